@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running THE REFERENCE ITSELF.
+
+Runs only in the authoring container (needs /root/reference and `transformers`);
+nothing of the reference is copied: the script imports its modules, loads the
+deterministic synthetic state dict of dinov2_od_amd.synth into the reference's
+own nn.Modules, runs their eval-mode fp32 CPU forward and stores inputs' seeds
+and the resulting outputs (.npz, data only).
+
+  python tests/golden/make_goldens.py [--only NAME]
+
+Obstacles handled exactly as SURVEY.md section 8c records (ordinary Python errors,
+no refused command): `pycocotools` / `tensorboard` are absent but only imported by
+the reference's eval/logging helpers -> empty stub modules; there is no network
+and no cached checkpoint -> `Dinov2Model.from_pretrained` is patched to build
+the architecture from an explicit `Dinov2Config` (weights then come from synth).
+"""
+import argparse
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+
+
+def _import_reference():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    stub("pycocotools")
+    stub("pycocotools.coco", COCO=type("COCO", (), {}))
+    stub("pycocotools.cocoeval", COCOeval=type("COCOeval", (), {}))
+    try:
+        import torch.utils.tensorboard  # noqa: F401
+    except Exception:
+        stub("torch.utils.tensorboard", SummaryWriter=type("SummaryWriter", (), {}))
+    sys.path.insert(0, REF)
+    import transformers
+    from transformers import Dinov2Config, Dinov2Model
+    return transformers, Dinov2Config, Dinov2Model
+
+
+transformers, Dinov2Config, Dinov2Model = _import_reference()
+
+from dinov2_od_amd.config import BackboneConfig, DecoderConfig  # noqa: E402
+from dinov2_od_amd import synth  # noqa: E402
+
+_BB_FOR_PATCH = {}
+
+
+def _patched_from_pretrained(name, *a, **k):
+    bb = _BB_FOR_PATCH["bb"]
+    cfg = Dinov2Config(image_size=bb.pos_grid * bb.patch, patch_size=bb.patch, hidden_size=bb.hidden,
+                       num_hidden_layers=bb.layers, num_attention_heads=bb.heads,
+                       mlp_ratio=bb.mlp_ratio, use_swiglu_ffn=bb.swiglu, layer_norm_eps=bb.ln_eps)
+    return Dinov2Model(cfg)
+
+
+Dinov2Model.from_pretrained = staticmethod(_patched_from_pretrained)
+
+from dino_detector.models import DINOv2ObjectDetector, DINOv2Backbone, DETRDecoder  # noqa: E402
+
+
+def _load(module, sd_np, strip=""):
+    sd = {k[len(strip):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()
+          if k.startswith(strip)}
+    missing, unexpected = module.load_state_dict(sd, strict=True), None
+    return missing
+
+
+def _meta():
+    return dict(torch=torch.__version__, transformers=transformers.__version__, numpy=np.__version__,
+                generator="dinov2_od_amd.synth v1")
+
+
+def _save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    meta = _meta()
+    np.savez_compressed(path, meta=np.array(repr(meta)), **arrs)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------ cases
+def micro_bb(swiglu=False):
+    return BackboneConfig(hidden=128, layers=2, heads=2, swiglu=swiglu, pos_grid=5, lora_r=2,
+                          lora_alpha=1.0, target_dim=0)
+
+
+def g0_micro_backbone(swiglu=False):
+    """G0 / G4: micro backbone through the reference's DINOv2Backbone; 70x70 (no
+    pos-embed resize, N=26) and 56x56 (bicubic 5->4, N=17).  Every block output kept."""
+    bb = micro_bb(swiglu)
+    _BB_FOR_PATCH["bb"] = bb
+    m = DINOv2Backbone(model_name="micro", lora_r=bb.lora_r, lora_alpha=bb.lora_alpha, target_dim=None).eval()
+    sd = synth.backbone_state_dict(bb, seed=1, prefix="")
+    _load(m, sd)
+    out = {}
+    for R in (70, 56):
+        x = synth.make_pixels(2, R, R, seed=0)
+        taps = {}
+        hooks = [m.dino.embeddings.register_forward_hook(lambda mod, i, o: taps.__setitem__("embeddings", o))]
+        for li, layer in enumerate(m.dino.encoder.layer):
+            hooks.append(layer.register_forward_hook(
+                lambda mod, i, o, li=li: taps.__setitem__(f"block{li}", o[0] if isinstance(o, tuple) else o)))
+        with torch.no_grad():
+            f = m(torch.from_numpy(x))
+        for h in hooks:
+            h.remove()
+        out[f"features_{R}"] = f.numpy()
+        for k, v in taps.items():
+            out[f"{k}_{R}"] = v.detach().numpy()
+    _save("g4_micro_swiglu" if swiglu else "g0_micro_backbone", **out)
+
+
+def dec_cfg(deform, Dd=128, Hd=4, Q=7, layers=2, F=256, C=11, P=2):
+    return DecoderConfig(num_queries=Q, hidden_dim=Dd, nheads=Hd, num_layers=layers, num_classes=C,
+                         dim_feedforward=F, n_points=P, use_deformable=deform)
+
+
+G1_CASES = [  # (tag, deform, Dd, Hd, Q, N list)
+    ("d32", True, 128, 4, 7, (17, 26, 257, 1370)),
+    ("d96", True, 192, 2, 5, (26, 1370)),
+    ("s32", False, 128, 4, 7, (17, 257)),
+    ("s96", False, 192, 2, 5, (26,)),
+]
+
+
+def g1_memory(N, Dd, seed=3):
+    return synth.normal(seed, f"memory.{N}.{Dd}", (2, N, Dd), 1.0)
+
+
+def g1_decoder_only():
+    out = {}
+    for tag, deform, Dd, Hd, Q, Ns in G1_CASES:
+        dc = dec_cfg(deform, Dd, Hd, Q)
+        m = DETRDecoder(num_queries=dc.num_queries, hidden_dim=dc.hidden_dim, nheads=dc.nheads,
+                        num_decoder_layers=dc.num_layers, num_classes=dc.num_classes,
+                        dim_feedforward=dc.dim_feedforward, dropout=0.1, n_points=dc.n_points,
+                        use_deformable=deform).eval()
+        sd = synth.decoder_state_dict(dc, seed=1, prefix="")
+        _load(m, sd)
+        for N in Ns:
+            mem = g1_memory(N, Dd)
+            with torch.no_grad():
+                o = m(torch.from_numpy(mem))
+            out[f"{tag}_N{N}_logits"] = o["pred_logits"].numpy()
+            out[f"{tag}_N{N}_boxes"] = o["pred_boxes"].numpy()
+    _save("g1_decoder_only", **out)
+
+
+def _e2e(name, model_name, R, B, kwargs, probes=True):
+    from dinov2_od_amd.config import variant_of, BACKBONE_VARIANTS
+    hid = kwargs.get("hidden_dim", 768)
+    bb = BackboneConfig.from_name(model_name, lora_r=kwargs.get("lora_r", 2), lora_alpha=1.0, target_dim=hid)
+    _BB_FOR_PATCH["bb"] = bb
+    m = DINOv2ObjectDetector(dino_model_name=model_name, **kwargs).eval()
+    dc = DecoderConfig(num_queries=kwargs.get("num_queries", 50), hidden_dim=hid,
+                       nheads=kwargs.get("nheads", 8), num_layers=kwargs.get("num_decoder_layers", 3),
+                       num_classes=kwargs.get("num_classes", 91),
+                       dim_feedforward=kwargs.get("dim_feedforward", 1024),
+                       n_points=kwargs.get("n_points", 2), use_deformable=kwargs.get("use_deformable", True))
+    sd = synth.detector_state_dict(bb, dc, seed=1)
+    _load(m, sd)
+    x = synth.make_pixels(B, R, R, seed=0)
+    with torch.no_grad():
+        feats = m.backbone(torch.from_numpy(x))
+        o = m.decoder(feats)
+    f = feats.numpy()
+    arrs = dict(pred_logits=o["pred_logits"].numpy(), pred_boxes=o["pred_boxes"].numpy(),
+                feat_probe=f[:, ::max(1, f.shape[1] // 8), :64].copy(),
+                feat_stats=np.array([f.mean(), np.abs(f).mean(), np.sqrt((f.astype(np.float64) ** 2).sum())]))
+    _save(name, **arrs)
+
+
+def g2_cfg1():
+    """BASELINE.json configs[0]: --lightweight ViT-S/14 224x224, batch 2 (train.py:607-640 preset);
+    Q=25 (CLI preset) and Q=100 (as BASELINE.json states)."""
+    for Q in (25, 100):
+        _e2e(f"g2_cfg1_q{Q}", "facebook/dinov2-small", 224, 2,
+             dict(num_classes=91, hidden_dim=256, num_queries=Q, num_decoder_layers=2,
+                  dim_feedforward=512, lora_r=1, nheads=4))
+
+
+def g3_vitb():
+    for R in (224, 518):
+        _e2e(f"g3_vitb_{R}", "facebook/dinov2-base", R, 1, dict(num_queries=100))
+    _e2e("g3_vitb_224_dense", "facebook/dinov2-base", 224, 1, dict(num_queries=100, use_deformable=False))
+
+
+CASES = dict(g0=lambda: g0_micro_backbone(False), g4=lambda: g0_micro_backbone(True),
+             g1=g1_decoder_only, g2=g2_cfg1, g3=g3_vitb)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    for k, fn in CASES.items():
+        if a.only and a.only != k:
+            continue
+        print("==", k)
+        fn()

@@ -1,0 +1,89 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself
+(tests/golden/make_goldens.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from dinov2_od_amd import synth
+from oracle import dinodet_oracle as orc
+from tests import cases
+from tests.cases import rel_err
+
+TOL = 2e-5   # fp32 vs fp32, different summation order
+
+
+@pytest.mark.parametrize("swiglu", [False, True])
+def test_micro_backbone_all_stages(swiglu):
+    g = cases.golden("g4_micro_swiglu" if swiglu else "g0_micro_backbone")
+    bb = cases.micro_bb(swiglu)
+    sd = synth.backbone_state_dict(bb, seed=1, prefix="backbone.")
+    for R in (70, 56):
+        x = synth.make_pixels(2, R, R, seed=0)
+        taps = {}
+        f = orc.backbone_forward(sd, bb, x, taps=taps)
+        assert rel_err(taps["embeddings"].numpy(), g[f"embeddings_{R}"]) < TOL
+        for i in range(bb.layers):
+            assert rel_err(taps[f"block{i}"].numpy(), g[f"block{i}_{R}"]) < TOL
+        assert rel_err(f.numpy(), g[f"features_{R}"]) < TOL
+
+
+@pytest.mark.parametrize("case", cases.G1_CASES, ids=[c[0] for c in cases.G1_CASES])
+def test_decoder_only(case):
+    tag, deform, Dd, Hd, Q, Ns = case
+    g = cases.golden("g1_decoder_only")
+    dc = cases.dec_cfg(deform, Dd, Hd, Q)
+    sd = synth.decoder_state_dict(dc, seed=1, prefix="decoder.")
+    for N in Ns:
+        mem = cases.g1_memory(N, Dd)
+        with torch.no_grad():
+            logits, boxes = orc.decoder_forward(sd, dc, mem)
+        assert rel_err(logits.numpy(), g[f"{tag}_N{N}_logits"]) < 1e-4, (tag, N)
+        assert rel_err(boxes.numpy(), g[f"{tag}_N{N}_boxes"]) < 1e-4, (tag, N)
+
+
+@pytest.mark.parametrize("Q", [25, 100])
+def test_cfg1_end_to_end(Q):
+    g = cases.golden(f"g2_cfg1_q{Q}")
+    bb, dc = cases.cfg1(Q)
+    sd = synth.detector_state_dict(bb, dc, seed=1)
+    x = synth.make_pixels(2, 224, 224, seed=0)
+    out = orc.detector_forward(sd, bb, dc, x)
+    f = out["features"].numpy()
+    assert rel_err(f[:, ::max(1, f.shape[1] // 8), :64], g["feat_probe"]) < 1e-4
+    assert rel_err(out["pred_logits"].numpy(), g["pred_logits"]) < 1e-3
+    assert rel_err(out["pred_boxes"].numpy(), g["pred_boxes"]) < 1e-3
+
+
+@pytest.mark.parametrize("name,R,deform", [("g3_vitb_224", 224, True), ("g3_vitb_518", 518, True),
+                                           ("g3_vitb_224_dense", 224, False)])
+def test_vitb_end_to_end(name, R, deform):
+    g = cases.golden(name)
+    bb, dc = cases.vitb(100, deform)
+    sd = synth.detector_state_dict(bb, dc, seed=1)
+    x = synth.make_pixels(1, R, R, seed=0)
+    out = orc.detector_forward(sd, bb, dc, x)
+    f = out["features"].numpy()
+    assert rel_err(f[:, ::max(1, f.shape[1] // 8), :64], g["feat_probe"]) < 1e-4
+    assert rel_err(out["pred_logits"].numpy(), g["pred_logits"]) < 1e-3
+    assert rel_err(out["pred_boxes"].numpy(), g["pred_boxes"]) < 1e-3
+
+
+def test_spatial_factor_quirk():
+    """(h,w) includes the CLS token: deformable_attention.py:241-256."""
+    from dinov2_od_amd.config import spatial_factor
+    assert spatial_factor(257) == (1, 257)
+    assert spatial_factor(1370) == (10, 137)
+    assert spatial_factor(26) == (2, 13)
+    assert spatial_factor(17) == (1, 17)
+    assert spatial_factor(256) == (16, 16)
+
+
+def test_bicubic_restatement_matches_torch():
+    src = torch.from_numpy(synth.normal(5, "bicubic", (3, 5, 5), 1.0))
+    want = torch.nn.functional.interpolate(src[None], size=(4, 4), mode="bicubic", align_corners=False)[0]
+    got = orc.bicubic_resize_ref(src, 4, 4)
+    assert rel_err(got.numpy(), want.numpy()) < 1e-6
+    src = torch.from_numpy(synth.normal(5, "bicubic37", (2, 37, 37), 1.0))
+    want = torch.nn.functional.interpolate(src[None], size=(16, 16), mode="bicubic", align_corners=False)[0]
+    got = orc.bicubic_resize_ref(src, 16, 16)
+    assert rel_err(got.numpy(), want.numpy()) < 1e-6
