@@ -1,0 +1,82 @@
+"""Build libdinodet.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m dinov2_od_amd._build [--force]
+
+hipcc cross-compiles without a GPU.  Objects go to build/obj, the library to
+dinov2_od_amd/lib/libdinodet.so (git-ignored, but it travels with the gpurun snapshot).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libdinodet.so")
+OBJ = os.path.join(ROOT, "build", "obj")
+SOURCES = ["dod_api.hip", "gemm_bf16.hip", "gemm_f32.hip", "attn_bf16.hip", "attn_f32.hip", "rowops.hip", "deform.hip"]
+HEADERS = [os.path.join(CSRC, "dod_common.h"), os.path.join(ROOT, "include", "dinodet.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-I" + os.path.join(ROOT, "include")]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src):
+    s = os.path.join(CSRC, src)
+    o = os.path.join(OBJ, src.replace(".hip", ".o"))
+    stamp = o + ".sha"
+    d = _digest([s] + HEADERS)
+    if os.path.exists(o) and os.path.exists(stamp) and open(stamp).read() == d:
+        return o, False
+    cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    with open(stamp, "w") as f:
+        f.write(d)
+    return o, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+        res = list(ex.map(_compile, SOURCES))
+    objs = [o for o, _ in res]
+    if any(ch for _, ch in res) or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"built {LIB}")
+    elif verbose:
+        print(f"{LIB} up to date")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

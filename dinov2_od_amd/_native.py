@@ -1,0 +1,97 @@
+"""ctypes binding of libdinodet.so (include/dinodet.h).  PyTorch is used only for device
+memory (tensor.data_ptr()) and the current HIP stream; no torch type crosses the ABI.
+
+There is NO fallback: if the library is missing or a GPU op is requested without it,
+loading raises.  Build with `python -m dinov2_od_amd._build`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdinodet.so")
+
+DOD_F32, DOD_BF16 = 0, 1
+PREC = {"fp32": 0, "bf16": 1}
+ACT = {"none": 0, "relu": 1, "gelu": 2, "sigmoid": 3}
+
+
+class DodConfig(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("swiglu", C.c_int32),
+        ("patch", C.c_int32), ("pos_grid", C.c_int32), ("ffn_hidden", C.c_int32), ("ln_eps", C.c_float),
+        ("lora_r", C.c_int32), ("lora_alpha", C.c_float), ("target_dim", C.c_int32),
+        ("num_queries", C.c_int32), ("dec_hidden", C.c_int32), ("dec_heads", C.c_int32),
+        ("dec_layers", C.c_int32), ("num_classes", C.c_int32), ("dim_feedforward", C.c_int32),
+        ("n_points", C.c_int32), ("use_deformable", C.c_int32), ("dec_ln_eps", C.c_float),
+        ("precision", C.c_int32),
+    ]
+
+
+_P, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes): every symbol include/dinodet.h declares
+SYMBOLS = {
+    "dod_create": (_I, [C.POINTER(DodConfig), C.POINTER(_P)]),
+    "dod_destroy": (None, [_P]),
+    "dod_last_error": (C.c_char_p, [_P]),
+    "dod_set_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "dod_finalize_weights": (_I, [_P, _P]),
+    "dod_prepare": (_I, [_P, _I, _I, _P]),
+    "dod_workspace_bytes": (_SZ, [_P, _I, _I, _I]),
+    "dod_num_tokens": (_I, [_P, _I, _I]),
+    "dod_forward": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
+    "dod_backbone_forward": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
+    "dod_decoder_forward": (_I, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
+    "dod_decoder_workspace_bytes": (_SZ, [_P, _I, _I]),
+    "dod_set_tap": (_I, [_P, _I, _P]),
+    "dod_op_linear": (_I, [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "dod_op_layernorm": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _I, _P]),
+    "dod_op_attention_bf16": (_I, [_P, _P, _I, _I, _I, _F, _P]),
+    "dod_op_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "dod_op_deform_sample": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dod_op_pos_resize": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "dod_op_im2col": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "dod_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+                "Build it with `python -m dinov2_od_amd._build`.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class DodError(RuntimeError):
+    pass
+
+
+_EXC = {1: ValueError, 2: KeyError, 3: RuntimeError, 4: RuntimeError}
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        msg = lib().dod_last_error(handle)
+        msg = msg.decode() if msg else f"dinodet error {rc}"
+        raise _EXC.get(rc, DodError)(msg)
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

@@ -1,0 +1,691 @@
+// Host side of libdinodet.so: handle, weight packing, workspace carving, the forward schedule, C ABI.
+// See include/dinodet.h for the contract.  Reference call stack being replaced: SURVEY.md section 3.1.
+#include "dod_common.h"
+#include "../../include/dinodet.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+int launch_widen_bf16(const bf16_t* in, float* out, size_t n, hipStream_t s);   // debug taps only (defined below)
+
+namespace {
+
+struct WRef { const float* ptr; std::vector<int64_t> shape; size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; } };
+
+struct BLayer {
+  void *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;   // bf16 or fp32 by precision
+  float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+  float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
+};
+struct DLayer {
+  float *in_w = nullptr, *in_b = nullptr, *out_w = nullptr, *out_b = nullptr;
+  float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr, *n3w = nullptr, *n3b = nullptr;
+  float *l1w = nullptr, *l1b = nullptr, *l2w = nullptr, *l2b = nullptr;
+  // deformable
+  float *cat_w = nullptr, *cat_b = nullptr, *op_w = nullptr, *op_b = nullptr, *vp_b = nullptr;
+  void* vp_w = nullptr;            // bf16 / fp32
+  int vp_alias = -1;               // index of an earlier layer with the same (tied) value_proj, or -1
+  // standard branch cross attention
+  float *ca_q_w = nullptr, *ca_q_b = nullptr, *ca_kv_b = nullptr, *ca_out_w = nullptr, *ca_out_b = nullptr;
+  void* ca_kv_w = nullptr;         // bf16 / fp32 [2Dd, Dd]
+};
+
+}  // namespace
+
+struct dod_handle {
+  dod_config cfg;
+  std::map<std::string, WRef> w;
+  mutable std::string err;
+  bool finalized = false;
+  bool has_bb = false, has_dec = false;   // which halves of the state dict were registered
+  std::vector<void*> owned;
+  // packed
+  std::vector<BLayer> L;
+  void* Wpatch = nullptr; int Kp = 0;
+  float *bpatch = nullptr, *cls = nullptr, *pos = nullptr, *lnfw = nullptr, *lnfb = nullptr, *bproj = nullptr;
+  void* Wproj = nullptr;
+  std::vector<DLayer> DL;
+  float *query = nullptr, *cls_w = nullptr, *cls_b = nullptr, *bb0_w = nullptr, *bb0_b = nullptr, *bb2_w = nullptr, *bb2_b = nullptr;
+  int ncat = 0;
+  // position-table cache
+  int pos_H = -1, pos_W = -1; float* pos_hw = nullptr; size_t pos_hw_elems = 0;
+  std::map<int, float*> taps;
+};
+
+namespace {
+
+std::string g_err;
+
+int fail(const dod_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (h) h->err = buf; else g_err = buf;
+  return code;
+}
+#define HIPCHK(h, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(h, DOD_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+#define KCHK(h, x) do { int r_ = (x); if (r_) return fail(h, r_ == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "kernel launch failed (%d): %s", r_, #x); } while (0)
+
+inline bool is_bf16(const dod_handle* h) { return h->cfg.precision == DOD_PREC_BF16; }
+inline size_t esz(const dod_handle* h) { return is_bf16(h) ? 2 : 4; }
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+void spatial_factor(int hw, int* h, int* w) {   // deformable_attention.py:241-256
+  int s = (int)std::sqrt((double)hw);
+  while ((s + 1) * (s + 1) <= hw) ++s;
+  while (s * s > hw) --s;
+  if (s * s != hw) {
+    for (int i = s; i > 0; --i) if (hw % i == 0) { *h = i; *w = hw / i; return; }
+  }
+  *h = s; *w = s;
+}
+
+// ------------------------------------------------------------------------------------------- weight packing
+struct Packer {
+  dod_handle* h; hipStream_t s; std::vector<void*> tmp; int rc = 0;
+  template <typename T> T* alloc(size_t n, bool temp = false) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n * sizeof(T) ? n * sizeof(T) : 4) != hipSuccess) { rc = fail(h, DOD_ERR_HIP, "hipMalloc of %zu bytes failed", n * sizeof(T)); return nullptr; }
+    (temp ? tmp : h->owned).push_back(p);
+    return (T*)p;
+  }
+  const WRef* find(const std::string& k) { auto it = h->w.find(k); return it == h->w.end() ? nullptr : &it->second; }
+  const WRef* need(const std::string& k, std::initializer_list<int64_t> shape) {
+    const WRef* r = find(k);
+    if (!r) { if (!rc) rc = fail(h, DOD_ERR_MISSING, "missing weight '%s'", k.c_str()); return nullptr; }
+    if (r->shape != std::vector<int64_t>(shape)) {
+      if (!rc) { std::string got; for (auto d : r->shape) got += std::to_string(d) + ","; rc = fail(h, DOD_ERR_INVALID, "weight '%s' has shape [%s] (unexpected)", k.c_str(), got.c_str()); }
+      return nullptr;
+    }
+    return r;
+  }
+  // owned fp32 copy of a vector/matrix parameter
+  float* copy(const std::string& k, std::initializer_list<int64_t> shape) {
+    const WRef* r = need(k, shape); if (!r) return nullptr;
+    float* d = alloc<float>(r->numel()); if (!d) return nullptr;
+    if (hipMemcpyAsync(d, r->ptr, r->numel() * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail(h, DOD_ERR_HIP, "copy of '%s' failed", k.c_str());
+    return d;
+  }
+  // effective fp32 weight of a (possibly LoRA-wrapped) linear: returns a device pointer valid until finalize ends
+  const float* eff_weight(const std::string& prefix, int out_f, int in_f) {
+    if (find(prefix + ".linear.weight")) {   // LoraLinear, dino_detector/utils.py:46-70
+      const WRef* W = need(prefix + ".linear.weight", {out_f, in_f});
+      const WRef* A = find(prefix + ".lora_A.weight");
+      const WRef* Bm = find(prefix + ".lora_B.weight");
+      if (!W) return nullptr;
+      if (!A || !Bm) { rc = fail(h, DOD_ERR_MISSING, "missing lora_A/lora_B for '%s'", prefix.c_str()); return nullptr; }
+      const int r = (int)A->shape[0];
+      if (A->shape != std::vector<int64_t>{r, in_f} || Bm->shape != std::vector<int64_t>{out_f, r}) { rc = fail(h, DOD_ERR_INVALID, "bad LoRA shapes for '%s'", prefix.c_str()); return nullptr; }
+      float* m = alloc<float>((size_t)out_f * in_f, true); if (!m) return nullptr;
+      if (launch_lora_merge(W->ptr, A->ptr, Bm->ptr, h->cfg.lora_alpha, out_f, in_f, r, m, s)) rc = fail(h, DOD_ERR_HIP, "lora merge launch failed");
+      return m;
+    }
+    const WRef* W = need(prefix + ".weight", {out_f, in_f});
+    return W ? W->ptr : nullptr;
+  }
+  float* eff_bias(const std::string& prefix, int out_f) {
+    if (find(prefix + ".linear.bias")) return copy(prefix + ".linear.bias", {out_f});
+    return copy(prefix + ".bias", {out_f});
+  }
+  // pack fp32 [rows, cols] (ld = cols) into the precision's operand dtype, K padded to cols_pad
+  void* pack_operand(const float* src, int rows, int cols, int cols_pad, bool force_f32 = false) {
+    if (!src) return nullptr;
+    const bool bf = is_bf16(h) && !force_f32;
+    float* f = alloc<float>((size_t)rows * cols_pad, bf); if (!f) return nullptr;
+    if (launch_copy2d(src, cols, f, cols_pad, rows, cols, cols_pad, s)) { rc = fail(h, DOD_ERR_HIP, "copy2d failed"); return nullptr; }
+    if (!bf) return f;
+    bf16_t* b = alloc<bf16_t>((size_t)rows * cols_pad); if (!b) return nullptr;
+    if (launch_cast_bf16(f, b, (size_t)rows * cols_pad, s)) { rc = fail(h, DOD_ERR_HIP, "cast failed"); return nullptr; }
+    return b;
+  }
+};
+
+int finalize_impl(dod_handle* h, hipStream_t s) {
+  for (void* p : h->owned) (void)hipFree(p);
+  h->owned.clear(); h->L.clear(); h->DL.clear(); h->finalized = false;
+  h->pos_H = h->pos_W = -1; h->pos_hw = nullptr; h->pos_hw_elems = 0;
+  const dod_config& c = h->cfg;
+  Packer P{h, s};
+  const int D = c.hidden, F = c.ffn_hidden, G = c.pos_grid, p = c.patch;
+  const std::string bb = "backbone.dino.", e = bb + "embeddings.";
+  h->has_bb = h->has_dec = false;
+  for (auto& kv : h->w) {
+    if (kv.first.rfind("backbone.", 0) == 0) h->has_bb = true;
+    if (kv.first.rfind("decoder.", 0) == 0) h->has_dec = true;
+  }
+  if (!h->has_bb && !h->has_dec) return fail(h, DOD_ERR_MISSING, "no 'backbone.*' or 'decoder.*' weights were registered");
+  if (!h->has_bb) goto decoder_part;
+  // ---- embeddings
+  h->cls = P.copy(e + "cls_token", {1, 1, D});
+  h->pos = P.copy(e + "position_embeddings", {1, (int64_t)G * G + 1, D});
+  h->bpatch = P.copy(e + "patch_embeddings.projection.bias", {D});
+  {
+    const WRef* W = P.need(e + "patch_embeddings.projection.weight", {D, 3, p, p});
+    const int K = 3 * p * p;
+    h->Kp = is_bf16(h) ? (K + 63) / 64 * 64 : K;
+    if (W) h->Wpatch = P.pack_operand(W->ptr, D, K, h->Kp);
+  }
+  // ---- encoder blocks
+  h->L.resize(c.layers);
+  for (int i = 0; i < c.layers && !P.rc; ++i) {
+    BLayer& L = h->L[i];
+    const std::string lp = bb + "encoder.layer." + std::to_string(i) + ".";
+    L.ln1w = P.copy(lp + "norm1.weight", {D}); L.ln1b = P.copy(lp + "norm1.bias", {D});
+    L.ln2w = P.copy(lp + "norm2.weight", {D}); L.ln2b = P.copy(lp + "norm2.bias", {D});
+    L.ls1 = P.copy(lp + "layer_scale1.lambda1", {D}); L.ls2 = P.copy(lp + "layer_scale2.lambda1", {D});
+    // fused QKV: rows [q | k | v]
+    float* cat = P.alloc<float>((size_t)3 * D * D, true);
+    L.bqkv = P.alloc<float>((size_t)3 * D);
+    const char* names[3] = {"query", "key", "value"};
+    for (int t = 0; t < 3 && !P.rc; ++t) {
+      const std::string q = lp + "attention.attention." + names[t];
+      const float* w = P.eff_weight(q, D, D);
+      float* b = P.eff_bias(q, D);
+      if (!w || !b || !cat || !L.bqkv) break;
+      HIPCHK(h, hipMemcpyAsync(cat + (size_t)t * D * D, w, (size_t)D * D * 4, hipMemcpyDeviceToDevice, s));
+      HIPCHK(h, hipMemcpyAsync(L.bqkv + (size_t)t * D, b, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (P.rc) break;
+    L.Wqkv = P.pack_operand(cat, 3 * D, D, D);
+    L.Wo = P.pack_operand(P.eff_weight(lp + "attention.output.dense", D, D), D, D, D);
+    L.bo = P.eff_bias(lp + "attention.output.dense", D);
+    if (c.swiglu) {
+      L.W1 = P.pack_operand(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, D);
+      L.b1 = P.eff_bias(lp + "mlp.weights_in", 2 * F);
+      L.W2 = P.pack_operand(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, F);
+      L.b2 = P.eff_bias(lp + "mlp.weights_out", D);
+    } else {
+      L.W1 = P.pack_operand(P.eff_weight(lp + "mlp.fc1", F, D), F, D, D);
+      L.b1 = P.eff_bias(lp + "mlp.fc1", F);
+      L.W2 = P.pack_operand(P.eff_weight(lp + "mlp.fc2", D, F), D, F, F);
+      L.b2 = P.eff_bias(lp + "mlp.fc2", D);
+    }
+  }
+  if (P.rc) goto done;
+  h->lnfw = P.copy(bb + "layernorm.weight", {D}); h->lnfb = P.copy(bb + "layernorm.bias", {D});
+  if (c.target_dim) {
+    const WRef* W = P.need("backbone.projection.weight", {c.target_dim, D});
+    if (W) h->Wproj = P.pack_operand(W->ptr, c.target_dim, D, D);
+    h->bproj = P.copy("backbone.projection.bias", {c.target_dim});
+  }
+decoder_part:
+  // ---- decoder (fp32 except the memory-side projections in bf16 mode)
+  if (h->has_dec) {
+    const int Dd = c.dec_hidden, Q = c.num_queries, Hd = c.dec_heads, Pn = c.n_points, Fd = c.dim_feedforward, C = c.num_classes;
+    const std::string dp = "decoder.";
+    h->query = P.copy(dp + "query_embed.weight", {Q, Dd});
+    h->cls_w = P.copy(dp + "class_embed.weight", {C, Dd}); h->cls_b = P.copy(dp + "class_embed.bias", {C});
+    h->bb0_w = P.copy(dp + "bbox_embed.mlp.0.weight", {Dd / 2, Dd}); h->bb0_b = P.copy(dp + "bbox_embed.mlp.0.bias", {Dd / 2});
+    h->bb2_w = P.copy(dp + "bbox_embed.mlp.2.weight", {4, Dd / 2}); h->bb2_b = P.copy(dp + "bbox_embed.mlp.2.bias", {4});
+    h->ncat = 2 + 3 * Hd * Pn;
+    h->DL.resize(c.dec_layers);
+    for (int j = 0; j < c.dec_layers && !P.rc; ++j) {
+      DLayer& L = h->DL[j];
+      const std::string lp = dp + "decoder.layers." + std::to_string(j) + ".";
+      L.in_w = P.copy(lp + "self_attn.in_proj_weight", {3 * Dd, Dd}); L.in_b = P.copy(lp + "self_attn.in_proj_bias", {3 * Dd});
+      L.out_w = P.copy(lp + "self_attn.out_proj.weight", {Dd, Dd}); L.out_b = P.copy(lp + "self_attn.out_proj.bias", {Dd});
+      L.n1w = P.copy(lp + "norm1.weight", {Dd}); L.n1b = P.copy(lp + "norm1.bias", {Dd});
+      L.n2w = P.copy(lp + "norm2.weight", {Dd}); L.n2b = P.copy(lp + "norm2.bias", {Dd});
+      L.n3w = P.copy(lp + "norm3.weight", {Dd}); L.n3b = P.copy(lp + "norm3.bias", {Dd});
+      L.l1w = P.copy(lp + "linear1.weight", {Fd, Dd}); L.l1b = P.copy(lp + "linear1.bias", {Fd});
+      L.l2w = P.copy(lp + "linear2.weight", {Dd, Fd}); L.l2b = P.copy(lp + "linear2.bias", {Dd});
+      if (c.use_deformable) {
+        // one fused small linear: [reference_points_proj (2) | sampling_offsets (Hd*P*2) | attention_weights (Hd*P)]
+        const WRef* rw = P.need(lp + "reference_points_proj.weight", {2, Dd});
+        const WRef* rb = P.need(lp + "reference_points_proj.bias", {2});
+        const WRef* ow = P.need(lp + "cross_attn.sampling_offsets.weight", {(int64_t)Hd * Pn * 2, Dd});
+        const WRef* ob = P.need(lp + "cross_attn.sampling_offsets.bias", {(int64_t)Hd * Pn * 2});
+        const WRef* aw = P.need(lp + "cross_attn.attention_weights.weight", {(int64_t)Hd * Pn, Dd});
+        const WRef* ab = P.need(lp + "cross_attn.attention_weights.bias", {(int64_t)Hd * Pn});
+        L.cat_w = P.alloc<float>((size_t)h->ncat * Dd); L.cat_b = P.alloc<float>(h->ncat);
+        if (P.rc || !rw || !rb || !ow || !ob || !aw || !ab || !L.cat_w || !L.cat_b) break;
+        HIPCHK(h, hipMemcpyAsync(L.cat_w, rw->ptr, (size_t)2 * Dd * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(L.cat_w + (size_t)2 * Dd, ow->ptr, (size_t)Hd * Pn * 2 * Dd * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(L.cat_w + (size_t)(2 + Hd * Pn * 2) * Dd, aw->ptr, (size_t)Hd * Pn * Dd * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(L.cat_b, rb->ptr, 2 * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(L.cat_b + 2, ob->ptr, (size_t)Hd * Pn * 2 * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(L.cat_b + 2 + Hd * Pn * 2, ab->ptr, (size_t)Hd * Pn * 4, hipMemcpyDeviceToDevice, s));
+        L.op_w = P.copy(lp + "cross_attn.output_proj.weight", {Dd, Dd}); L.op_b = P.copy(lp + "cross_attn.output_proj.bias", {Dd});
+        // value projection: layers are weight-tied in the reference (deformable_attention.py:284): when the
+        // caller registered the same storage for several layers the projection is computed once per forward
+        const WRef* vw = P.need(lp + "cross_attn.value_proj.weight", {Dd, Dd});
+        const WRef* vb = P.need(lp + "cross_attn.value_proj.bias", {Dd});
+        if (!vw || !vb) break;
+        for (int k = 0; k < j; ++k) {
+          const std::string kp = dp + "decoder.layers." + std::to_string(k) + ".";
+          if (h->w[kp + "cross_attn.value_proj.weight"].ptr == vw->ptr && h->w[kp + "cross_attn.value_proj.bias"].ptr == vb->ptr) { L.vp_alias = h->DL[k].vp_alias >= 0 ? h->DL[k].vp_alias : k; break; }
+        }
+        if (L.vp_alias < 0) { L.vp_w = P.pack_operand(vw->ptr, Dd, Dd, Dd); L.vp_b = P.copy(lp + "cross_attn.value_proj.bias", {Dd}); }
+      } else {
+        const WRef* iw = P.need(lp + "multihead_attn.in_proj_weight", {3 * Dd, Dd});
+        const WRef* ib = P.need(lp + "multihead_attn.in_proj_bias", {3 * Dd});
+        if (!iw || !ib) break;
+        L.ca_q_w = (float*)P.pack_operand(iw->ptr, Dd, Dd, Dd, true);
+        L.ca_kv_w = P.pack_operand(iw->ptr + (size_t)Dd * Dd, 2 * Dd, Dd, Dd);
+        L.ca_q_b = P.alloc<float>(Dd); L.ca_kv_b = P.alloc<float>(2 * Dd);
+        if (P.rc) break;
+        HIPCHK(h, hipMemcpyAsync(L.ca_q_b, ib->ptr, (size_t)Dd * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(L.ca_kv_b, ib->ptr + Dd, (size_t)2 * Dd * 4, hipMemcpyDeviceToDevice, s));
+        L.ca_out_w = P.copy(lp + "multihead_attn.out_proj.weight", {Dd, Dd}); L.ca_out_b = P.copy(lp + "multihead_attn.out_proj.bias", {Dd});
+      }
+    }
+  }
+done:
+  hipError_t se = hipStreamSynchronize(s);
+  for (void* t : P.tmp) (void)hipFree(t);
+  if (P.rc) return P.rc;
+  if (se != hipSuccess) return fail(h, DOD_ERR_HIP, "finalize: %s", hipGetErrorString(se));
+  h->finalized = true;
+  return DOD_OK;
+}
+
+// ------------------------------------------------------------------------------------------- workspace
+struct Carver {
+  char* base; size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  void* take(size_t bytes) { void* p = base ? base + off : nullptr; off += align_up(bytes); return p; }
+};
+
+struct DecWS { float *tgt, *t2, *att, *samp, *qkv, *proj, *ffn, *hb, *qd; void* mem_op; float* values; float* kv; };
+struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; };
+
+size_t carve_decoder(const dod_handle* h, Carver& c, int B, int N, DecWS* w, bool need_mem_op) {
+  const dod_config& g = h->cfg;
+  const size_t BQ = (size_t)B * g.num_queries, Dd = g.dec_hidden, M = (size_t)B * N;
+  DecWS t;
+  t.tgt = (float*)c.take(BQ * Dd * 4); t.t2 = (float*)c.take(BQ * Dd * 4); t.att = (float*)c.take(BQ * Dd * 4);
+  t.samp = (float*)c.take(BQ * Dd * 4); t.qkv = (float*)c.take(BQ * 3 * Dd * 4);
+  t.proj = (float*)c.take(BQ * (size_t)(h->ncat > 0 ? h->ncat : 4) * 4);
+  t.ffn = (float*)c.take(BQ * (size_t)g.dim_feedforward * 4); t.hb = (float*)c.take(BQ * (Dd / 2) * 4);
+  t.qd = (float*)c.take(BQ * Dd * 4);
+  t.mem_op = need_mem_op ? c.take(M * Dd * esz(h)) : nullptr;
+  if (g.use_deformable) {
+    int uniq = 0; for (auto& L : h->DL) if (L.vp_alias < 0) ++uniq;
+    if (!h->finalized) uniq = g.dec_layers;
+    t.values = (float*)c.take(M * Dd * 4 * (size_t)(uniq > 0 ? uniq : 1)); t.kv = nullptr;
+  } else {
+    t.values = nullptr; t.kv = (float*)c.take(M * 2 * Dd * 4);
+  }
+  if (w) *w = t;
+  return c.off;
+}
+
+size_t carve_backbone(const dod_handle* h, Carver& c, int B, int N, BbWS* w) {
+  const dod_config& g = h->cfg;
+  const size_t M = (size_t)B * N, D = g.hidden, es = esz(h), Np = N - 1;
+  const size_t F1 = g.swiglu ? 2 * (size_t)g.ffn_hidden : (size_t)g.ffn_hidden;
+  size_t hb = M * F1; const size_t col = (size_t)B * Np * (size_t)(h->Kp ? h->Kp : (3 * g.patch * g.patch + 63) / 64 * 64);
+  if (col > hb) hb = col;
+  BbWS t;
+  t.x = (float*)c.take(M * D * 4); t.y = c.take(M * D * es); t.qkv = c.take(M * 3 * D * es); t.ctx = c.take(M * D * es);
+  t.hbuf = c.take(hb * es); t.gated = g.swiglu ? c.take(M * (size_t)g.ffn_hidden * es) : nullptr;
+  t.mem = c.take(M * (size_t)(g.target_dim ? g.target_dim : g.hidden) * es);
+  if (w) *w = t;
+  return c.off;
+}
+
+int prepare_impl(dod_handle* h, int H, int W, hipStream_t s) {
+  const dod_config& g = h->cfg;
+  if (!h->finalized || !h->has_bb) return fail(h, DOD_ERR_STATE, "backbone weights not finalized");
+  if (H < g.patch || W < g.patch) return fail(h, DOD_ERR_INVALID, "image %dx%d smaller than one patch", H, W);
+  if (h->pos_H == H && h->pos_W == W) return DOD_OK;
+  const int gh = H / g.patch, gw = W / g.patch;
+  // modeling_dinov2.py:71-72: used as is only when num_patches == num_positions and H == W
+  if (gh * gw == g.pos_grid * g.pos_grid && H == W) { h->pos_hw = h->pos; h->pos_H = H; h->pos_W = W; return DOD_OK; }
+  const size_t need = (size_t)(gh * gw + 1) * g.hidden;
+  float* buf = nullptr;
+  HIPCHK(h, hipMalloc((void**)&buf, need * 4));
+  h->owned.push_back(buf);
+  KCHK(h, launch_pos_resize(h->pos, g.pos_grid, gh, gw, g.hidden, buf, s));
+  h->pos_hw = buf; h->pos_hw_elems = need; h->pos_H = H; h->pos_W = W;
+  return DOD_OK;
+}
+
+int tap(dod_handle* h, int stage, const void* src, bool src_bf16, size_t n, hipStream_t s);
+
+// generic linear on the precision's operand dtype
+int linear(dod_handle* h, bool bf, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+  int r = bf ? launch_gemm_bf16((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, e, s)
+             : launch_gemm_f32((const float*)A, lda, (const float*)W, ldw, M, N, K, e, s);
+  if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "linear launch rejected (M=%d N=%d K=%d bf16=%d rc=%d)", M, N, K, (int)bf, r);
+  return 0;
+}
+GemmEpi epi(const float* bias, float* of32, void* obf, int ldc, int act = ACT_NONE, const float* scale = nullptr, const float* resid = nullptr, int ldr = 0) {
+  GemmEpi e; memset(&e, 0, sizeof e);
+  e.bias = bias; e.out_f32 = of32; e.out_bf16 = (bf16_t*)obf; e.ldc = ldc; e.act = act; e.scale = scale; e.resid = resid; e.ldr = ldr;
+  return e;
+}
+
+// DINOv2Backbone.forward (dinov2_backbone.py:58-67) -> ws.mem (operand dtype) and/or feat_f32
+int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const BbWS& ws, float* feat_f32, bool want_mem, hipStream_t s) {
+  const dod_config& g = h->cfg;
+  const bool bf = is_bf16(h);
+  const int D = g.hidden, F = g.ffn_hidden, p = g.patch;
+  const int gh = H / p, gw = W / p, Np = gh * gw, N = Np + 1, M = B * N;
+  if (!h->has_bb) return fail(h, DOD_ERR_STATE, "no backbone weights were registered");
+  if (bf && D / g.heads != 64) return fail(h, DOD_ERR_INVALID, "bf16 attention kernel needs head_dim 64 (got %d)", D / g.heads);
+  int rc = prepare_impl(h, H, W, s); if (rc) return rc;
+  // K1 + K2: im2col -> GEMM with bias + position add, rows remapped past the CLS slot
+  KCHK(h, launch_im2col(pixels, B, H, W, p, h->Kp, bf ? nullptr : (float*)ws.hbuf, bf ? (bf16_t*)ws.hbuf : nullptr, s));
+  {
+    GemmEpi e = epi(h->bpatch, ws.x, nullptr, D);
+    e.pos = h->pos_hw; e.rows_per_img = Np; e.out_rows_per_img = N;
+    rc = linear(h, bf, ws.hbuf, h->Kp, h->Wpatch, h->Kp, B * Np, D, h->Kp, e, s); if (rc) return rc;
+  }
+  KCHK(h, launch_cls_row(h->cls, h->pos_hw, ws.x, B, N, D, s));
+  tap(h, 0, ws.x, false, (size_t)M * D, s);
+  const float scale = 1.0f / std::sqrt((float)(D / g.heads));
+  float* yf = bf ? nullptr : (float*)ws.y; bf16_t* yb = bf ? (bf16_t*)ws.y : nullptr;
+  for (int i = 0; i < g.layers; ++i) {
+    const BLayer& L = h->L[i];
+    KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, yf, yb, s));                       // K3
+    rc = linear(h, bf, ws.y, D, L.Wqkv, D, M, 3 * D, D, epi(L.bqkv, bf ? nullptr : (float*)ws.qkv, bf ? ws.qkv : nullptr, 3 * D), s); if (rc) return rc;  // K4
+    if (bf) { KCHK(h, launch_attn_bf16((const bf16_t*)ws.qkv, (bf16_t*)ws.ctx, B, N, g.heads, scale, s)); }    // K5
+    else {
+      AttnF32 a; const float* q = (const float*)ws.qkv;
+      a.q = q; a.k = q + D; a.v = q + 2 * D; a.o = (float*)ws.ctx; a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
+      a.Lq = a.Lk = N; a.B = B; a.heads = g.heads; a.dh = D / g.heads; a.scale = scale;
+      KCHK(h, launch_attn_f32(a, s));
+    }
+    rc = linear(h, bf, ws.ctx, D, L.Wo, D, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;   // K6
+    KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, yf, yb, s));
+    if (g.swiglu) {                                                                                            // K7g
+      rc = linear(h, bf, ws.y, D, L.W1, D, M, 2 * F, D, epi(L.b1, bf ? nullptr : (float*)ws.hbuf, bf ? ws.hbuf : nullptr, 2 * F), s); if (rc) return rc;
+      KCHK(h, launch_swiglu(bf ? nullptr : (const float*)ws.hbuf, bf ? (const bf16_t*)ws.hbuf : nullptr, M, F, bf ? nullptr : (float*)ws.gated, bf ? (bf16_t*)ws.gated : nullptr, s));
+      rc = linear(h, bf, ws.gated, F, L.W2, F, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
+    } else {                                                                                                   // K7
+      rc = linear(h, bf, ws.y, D, L.W1, D, M, F, D, epi(L.b1, bf ? nullptr : (float*)ws.hbuf, bf ? ws.hbuf : nullptr, F, ACT_GELU), s); if (rc) return rc;
+      rc = linear(h, bf, ws.hbuf, F, L.W2, F, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
+    }
+    tap(h, 1 + i, ws.x, false, (size_t)M * D, s);
+  }
+  // final LayerNorm (+ projection K9)
+  if (!g.target_dim) {
+    float* of = feat_f32 ? feat_f32 : (bf ? nullptr : (want_mem ? (float*)ws.mem : nullptr));
+    bf16_t* ob = (bf && want_mem) ? (bf16_t*)ws.mem : nullptr;
+    KCHK(h, launch_layernorm(ws.x, nullptr, h->lnfw, h->lnfb, g.ln_eps, M, D, of, ob, s));
+    if (!bf && want_mem && feat_f32) HIPCHK(h, hipMemcpyAsync(ws.mem, feat_f32, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    const int Dd = g.target_dim;
+    KCHK(h, launch_layernorm(ws.x, nullptr, h->lnfw, h->lnfb, g.ln_eps, M, D, yf, yb, s));
+    if (feat_f32) { rc = linear(h, bf, ws.y, D, h->Wproj, D, M, Dd, D, epi(h->bproj, feat_f32, nullptr, Dd), s); if (rc) return rc; }
+    if (want_mem) { rc = linear(h, bf, ws.y, D, h->Wproj, D, M, Dd, D, epi(h->bproj, bf ? nullptr : (float*)ws.mem, bf ? ws.mem : nullptr, Dd), s); if (rc) return rc; }
+  }
+  return DOD_OK;
+}
+
+// DETRDecoder.forward (detr_decoder.py:47-83).  mem_op: memory in the operand dtype (bf16 in fast mode).
+int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& ws, float* det, hipStream_t s) {
+  const dod_config& g = h->cfg;
+  const bool bf = is_bf16(h);
+  const int Dd = g.dec_hidden, Q = g.num_queries, Hd = g.dec_heads, Pn = g.n_points, Fd = g.dim_feedforward, C = g.num_classes;
+  const int BQ = B * Q, M = B * N, dh = Dd / Hd;
+  if (!h->has_dec) return fail(h, DOD_ERR_STATE, "no decoder weights were registered");
+  if (Dd % Hd) return fail(h, DOD_ERR_INVALID, "decoder hidden %d not divisible by heads %d", Dd, Hd);
+  if (dh > 128 || dh % 4) return fail(h, DOD_ERR_INVALID, "decoder head_dim %d unsupported (<=128, multiple of 4)", dh);
+  int rc;
+  tap(h, 1000, mem_op, bf, (size_t)M * Dd, s);
+  KCHK(h, launch_bcast_rows(h->query, ws.tgt, B, Q, Dd, s));                                                  // K10
+  int fh = 0, fw = 0;
+  if (g.use_deformable) {
+    spatial_factor(N, &fh, &fw);                                                                                // K16
+    int u = 0;
+    for (int j = 0; j < g.dec_layers; ++j) {                                                                    // K14 (once per distinct weight)
+      DLayer& L = h->DL[j];
+      if (L.vp_alias >= 0) continue;
+      float* dst = ws.values + (size_t)u * M * Dd; ++u;
+      rc = linear(h, bf, mem_op, Dd, L.vp_w, Dd, M, Dd, Dd, epi(L.vp_b, dst, nullptr, Dd), s); if (rc) return rc;
+    }
+    tap(h, 2000, ws.values, false, (size_t)M * Dd, s);
+  }
+  const float sscale = 1.0f / std::sqrt((float)dh);
+  auto self_attn = [&](const DLayer& L) -> int {                                                               // K11
+    int r = linear(h, false, ws.tgt, Dd, L.in_w, Dd, BQ, 3 * Dd, Dd, epi(L.in_b, ws.qkv, nullptr, 3 * Dd), s); if (r) return r;
+    AttnF32 a; a.q = ws.qkv; a.k = ws.qkv + Dd; a.v = ws.qkv + 2 * Dd; a.o = ws.att; a.ldq = a.ldk = a.ldv = 3 * Dd; a.ldo = Dd;
+    a.Lq = a.Lk = Q; a.B = B; a.heads = Hd; a.dh = dh; a.scale = sscale;
+    KCHK(h, launch_attn_f32(a, s));
+    r = linear(h, false, ws.att, Dd, L.out_w, Dd, BQ, Dd, Dd, epi(L.out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s); if (r) return r;
+    KCHK(h, launch_layernorm(ws.t2, nullptr, L.n1w, L.n1b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
+    return 0;
+  };
+  auto ffn = [&](const DLayer& L) -> int {                                                                     // K18
+    int r = linear(h, false, ws.tgt, Dd, L.l1w, Dd, BQ, Fd, Dd, epi(L.l1b, ws.ffn, nullptr, Fd, ACT_RELU), s); if (r) return r;
+    r = linear(h, false, ws.ffn, Fd, L.l2w, Fd, BQ, Dd, Fd, epi(L.l2b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s); if (r) return r;
+    KCHK(h, launch_layernorm(ws.t2, nullptr, L.n3w, L.n3b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
+    return 0;
+  };
+  int uniq_idx[64]; { int u = 0; for (int j = 0; j < g.dec_layers && j < 64; ++j) uniq_idx[j] = h->DL[j].vp_alias < 0 ? u++ : -1; }
+  for (int j = 0; j < g.dec_layers; ++j) {
+    const DLayer& L = h->DL[j];
+    rc = self_attn(L); if (rc) return rc;
+    if (g.use_deformable) {
+      // K12 + K13 fused small linear, then K15 gather
+      rc = linear(h, false, ws.tgt, Dd, L.cat_w, Dd, BQ, h->ncat, Dd, epi(L.cat_b, ws.proj, nullptr, h->ncat), s); if (rc) return rc;
+      const int src = L.vp_alias >= 0 ? L.vp_alias : j;
+      const float* vals = ws.values + (size_t)uniq_idx[src] * M * Dd;
+      KCHK(h, launch_deform_sample(ws.proj, h->ncat, vals, B, Q, N, Hd, Pn, dh, fh, fw, ws.samp, s));
+      rc = linear(h, false, ws.samp, Dd, L.op_w, Dd, BQ, Dd, Dd, epi(L.op_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s); if (rc) return rc;   // K17
+      KCHK(h, launch_layernorm(ws.t2, nullptr, L.n2w, L.n2b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
+    } else {
+      // K20: dense cross-attention over all N memory tokens
+      rc = linear(h, false, ws.tgt, Dd, L.ca_q_w, Dd, BQ, Dd, Dd, epi(L.ca_q_b, ws.qd, nullptr, Dd), s); if (rc) return rc;
+      rc = linear(h, bf, mem_op, Dd, L.ca_kv_w, Dd, M, 2 * Dd, Dd, epi(L.ca_kv_b, ws.kv, nullptr, 2 * Dd), s); if (rc) return rc;
+      AttnF32 a; a.q = ws.qd; a.k = ws.kv; a.v = ws.kv + Dd; a.o = ws.att; a.ldq = Dd; a.ldk = a.ldv = 2 * Dd; a.ldo = Dd;
+      a.Lq = Q; a.Lk = N; a.B = B; a.heads = Hd; a.dh = dh; a.scale = sscale;
+      KCHK(h, launch_attn_f32(a, s));
+      rc = linear(h, false, ws.att, Dd, L.ca_out_w, Dd, BQ, Dd, Dd, epi(L.ca_out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s); if (rc) return rc;
+      KCHK(h, launch_layernorm(ws.t2, nullptr, L.n2w, L.n2b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
+    }
+    rc = ffn(L); if (rc) return rc;
+    tap(h, 3000 + j, ws.tgt, false, (size_t)BQ * Dd, s);
+  }
+  // K19 heads -> packed [B, Q, C+4]
+  rc = linear(h, false, ws.tgt, Dd, h->cls_w, Dd, BQ, C, Dd, epi(h->cls_b, det, nullptr, C + 4), s); if (rc) return rc;
+  rc = linear(h, false, ws.tgt, Dd, h->bb0_w, Dd, BQ, Dd / 2, Dd, epi(h->bb0_b, ws.hb, nullptr, Dd / 2, ACT_RELU), s); if (rc) return rc;
+  rc = linear(h, false, ws.hb, Dd / 2, h->bb2_w, Dd / 2, BQ, 4, Dd / 2, epi(h->bb2_b, det + C, nullptr, C + 4, ACT_SIGMOID), s); if (rc) return rc;
+  return DOD_OK;
+}
+
+int tap(dod_handle* h, int stage, const void* src, bool src_bf16, size_t n, hipStream_t s) {
+  auto it = h->taps.find(stage);
+  if (it == h->taps.end() || !it->second) return 0;
+  if (!src_bf16) { (void)hipMemcpyAsync(it->second, src, n * 4, hipMemcpyDeviceToDevice, s); return 0; }
+  return launch_widen_bf16((const bf16_t*)src, it->second, n, s);
+}
+
+bool check_common(dod_handle* h, int B, int H, int W, int* rc) {
+  if (!h) { *rc = fail(nullptr, DOD_ERR_INVALID, "null handle"); return false; }
+  if (!h->finalized) { *rc = fail(h, DOD_ERR_STATE, "dod_finalize_weights has not been called"); return false; }
+  if (B <= 0) { *rc = fail(h, DOD_ERR_INVALID, "batch must be positive (got %d)", B); return false; }
+  if (H < h->cfg.patch || W < h->cfg.patch) { *rc = fail(h, DOD_ERR_INVALID, "image %dx%d smaller than one %dx%d patch", H, W, h->cfg.patch, h->cfg.patch); return false; }
+  return true;
+}
+
+}  // namespace
+
+// bf16 -> fp32 widening (debug taps only)
+__global__ void widen_bf16_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = bf2f(in[i]);
+}
+int launch_widen_bf16(const bf16_t* in, float* out, size_t n, hipStream_t s) {
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(widen_bf16_kernel, dim3(blocks), dim3(256), 0, s, in, out, n);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// =========================================================================================== C ABI
+extern "C" {
+
+const char* dod_version(void) { return "dinodet 0.1 (gfx950)"; }
+
+const char* dod_last_error(const dod_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int dod_create(const dod_config* cfg, dod_handle** out) {
+  if (!cfg || !out) return fail(nullptr, DOD_ERR_INVALID, "null argument");
+  const dod_config& c = *cfg;
+  if (c.hidden <= 0 || c.layers <= 0 || c.heads <= 0 || c.hidden % c.heads) return fail(nullptr, DOD_ERR_INVALID, "bad backbone dims hidden=%d heads=%d layers=%d", c.hidden, c.heads, c.layers);
+  if (c.hidden % 64 || c.ffn_hidden % 64) return fail(nullptr, DOD_ERR_INVALID, "hidden (%d) and ffn_hidden (%d) must be multiples of 64", c.hidden, c.ffn_hidden);
+  if (c.patch <= 0 || c.pos_grid <= 0) return fail(nullptr, DOD_ERR_INVALID, "bad patch/pos_grid");
+  if (c.num_queries <= 0 || c.dec_hidden <= 0 || c.dec_heads <= 0 || c.dec_layers <= 0 || c.num_classes <= 0 || c.dim_feedforward <= 0) return fail(nullptr, DOD_ERR_INVALID, "bad decoder dims");
+  if (c.dec_hidden % 64 || c.dim_feedforward % 4) return fail(nullptr, DOD_ERR_INVALID, "decoder hidden (%d) must be a multiple of 64, dim_feedforward (%d) of 4", c.dec_hidden, c.dim_feedforward);
+  if (c.target_dim && c.target_dim != c.dec_hidden) return fail(nullptr, DOD_ERR_INVALID, "projection dim %d != decoder hidden %d", c.target_dim, c.dec_hidden);
+  if (!c.target_dim && c.hidden != c.dec_hidden) return fail(nullptr, DOD_ERR_INVALID, "backbone width %d != decoder hidden %d and no projection", c.hidden, c.dec_hidden);
+  if (c.use_deformable && (c.n_points <= 0 || c.n_points > 8)) return fail(nullptr, DOD_ERR_INVALID, "n_points must be 1..8");
+  if (c.dec_layers > 64) return fail(nullptr, DOD_ERR_INVALID, "at most 64 decoder layers");
+  if (c.precision != DOD_PREC_FP32 && c.precision != DOD_PREC_BF16) return fail(nullptr, DOD_ERR_INVALID, "unknown precision %d", c.precision);
+  dod_handle* h = new (std::nothrow) dod_handle();
+  if (!h) return fail(nullptr, DOD_ERR_STATE, "out of host memory");
+  h->cfg = c;
+  *out = h;
+  return DOD_OK;
+}
+
+void dod_destroy(dod_handle* h) {
+  if (!h) return;
+  for (void* p : h->owned) (void)hipFree(p);
+  delete h;
+}
+
+int dod_set_weight(dod_handle* h, const char* key, const void* dev_ptr, const int64_t* shape, int ndim) {
+  if (!h || !key || !dev_ptr || ndim < 0 || ndim > 8 || (ndim && !shape)) return fail(h, DOD_ERR_INVALID, "dod_set_weight: bad argument");
+  std::string k(key);
+  if (k.rfind("module.", 0) == 0) k = k.substr(7);   // DDP prefix, train.py:700-709
+  WRef r; r.ptr = (const float*)dev_ptr; r.shape.assign(shape, shape + ndim);
+  h->w[k] = r;
+  h->finalized = false;
+  return DOD_OK;
+}
+
+int dod_finalize_weights(dod_handle* h, void* stream) {
+  if (!h) return fail(nullptr, DOD_ERR_INVALID, "null handle");
+  return finalize_impl(h, (hipStream_t)stream);
+}
+
+int dod_prepare(dod_handle* h, int H, int W, void* stream) {
+  if (!h) return fail(nullptr, DOD_ERR_INVALID, "null handle");
+  return prepare_impl(h, H, W, (hipStream_t)stream);
+}
+
+int dod_num_tokens(const dod_handle* h, int H, int W) { return h ? (H / h->cfg.patch) * (W / h->cfg.patch) + 1 : 0; }
+
+size_t dod_workspace_bytes(const dod_handle* h, int B, int H, int W) {
+  if (!h || B <= 0 || H < h->cfg.patch || W < h->cfg.patch) return 0;
+  const int N = dod_num_tokens(h, H, W);
+  Carver c(nullptr);
+  carve_backbone(h, c, B, N, nullptr);
+  carve_decoder(h, c, B, N, nullptr, false);
+  return c.off + 256;
+}
+
+size_t dod_decoder_workspace_bytes(const dod_handle* h, int B, int N) {
+  if (!h || B <= 0 || N <= 0) return 0;
+  Carver c(nullptr);
+  carve_decoder(h, c, B, N, nullptr, true);
+  return c.off + 256;
+}
+
+int dod_set_tap(dod_handle* h, int stage, float* dst) {
+  if (!h) return fail(nullptr, DOD_ERR_INVALID, "null handle");
+  if (dst) h->taps[stage] = dst; else h->taps.erase(stage);
+  return DOD_OK;
+}
+
+static void* align_ws(void* p) { return (void*)(((uintptr_t)p + 255) & ~(uintptr_t)255); }
+
+int dod_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* det, void* workspace, size_t wsb, void* stream) {
+  int rc;
+  if (!check_common(h, B, H, W, &rc)) return rc;
+  if (!pixels || !det || !workspace) return fail(h, DOD_ERR_INVALID, "null buffer");
+  if (wsb < dod_workspace_bytes(h, B, H, W)) return fail(h, DOD_ERR_STATE, "workspace too small: %zu < %zu", wsb, dod_workspace_bytes(h, B, H, W));
+  const int N = dod_num_tokens(h, H, W);
+  Carver c(align_ws(workspace));
+  BbWS bw; DecWS dw;
+  carve_backbone(h, c, B, N, &bw);
+  carve_decoder(h, c, B, N, &dw, false);
+  hipStream_t s = (hipStream_t)stream;
+  rc = backbone_impl(h, pixels, B, H, W, bw, nullptr, true, s); if (rc) return rc;
+  return decoder_impl(h, bw.mem, B, N, dw, det, s);
+}
+
+int dod_backbone_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* features, void* workspace, size_t wsb, void* stream) {
+  int rc;
+  if (!check_common(h, B, H, W, &rc)) return rc;
+  if (!pixels || !features || !workspace) return fail(h, DOD_ERR_INVALID, "null buffer");
+  if (wsb < dod_workspace_bytes(h, B, H, W)) return fail(h, DOD_ERR_STATE, "workspace too small: %zu < %zu", wsb, dod_workspace_bytes(h, B, H, W));
+  const int N = dod_num_tokens(h, H, W);
+  Carver c(align_ws(workspace));
+  BbWS bw;
+  carve_backbone(h, c, B, N, &bw);
+  return backbone_impl(h, pixels, B, H, W, bw, features, false, (hipStream_t)stream);
+}
+
+int dod_decoder_forward(dod_handle* h, const float* memory, int B, int N, float* det, void* workspace, size_t wsb, void* stream) {
+  if (!h) return fail(nullptr, DOD_ERR_INVALID, "null handle");
+  if (!h->finalized) return fail(h, DOD_ERR_STATE, "dod_finalize_weights has not been called");
+  if (B <= 0 || N <= 0) return fail(h, DOD_ERR_INVALID, "bad B=%d N=%d", B, N);
+  if (!memory || !det || !workspace) return fail(h, DOD_ERR_INVALID, "null buffer");
+  if (wsb < dod_decoder_workspace_bytes(h, B, N)) return fail(h, DOD_ERR_STATE, "workspace too small");
+  Carver c(align_ws(workspace));
+  DecWS dw;
+  carve_decoder(h, c, B, N, &dw, true);
+  hipStream_t s = (hipStream_t)stream;
+  const void* mem_op = memory;
+  if (is_bf16(h)) {
+    KCHK(h, launch_cast_bf16(memory, (bf16_t*)dw.mem_op, (size_t)B * N * h->cfg.dec_hidden, s));
+    mem_op = dw.mem_op;
+  }
+  return decoder_impl(h, mem_op, B, N, dw, det, s);
+}
+
+// ---- stateless ops
+int dod_op_linear(int in_dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
+                  const float* scale, const float* resid, int ldr, void* out, int out_dtype, int ldc, int act, void* stream) {
+  if (!A || !W || !out) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  GemmEpi e = epi(bias, out_dtype == DOD_F32 ? (float*)out : nullptr, out_dtype == DOD_BF16 ? out : nullptr, ldc, act, scale, resid, ldr);
+  int r = in_dtype == DOD_BF16 ? launch_gemm_bf16((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, e, (hipStream_t)stream)
+                               : launch_gemm_f32((const float*)A, lda, (const float*)W, ldw, M, N, K, e, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
+  return DOD_OK;
+}
+int dod_op_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps, int rows, int D, void* out, int out_dtype, void* stream) {
+  if (!x || !gamma || !beta || !out) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  int r = launch_layernorm(x, add, gamma, beta, eps, rows, D, out_dtype == DOD_F32 ? (float*)out : nullptr, out_dtype == DOD_BF16 ? (bf16_t*)out : nullptr, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_layernorm rejected rows=%d D=%d", rows, D);
+  return DOD_OK;
+}
+int dod_op_attention_bf16(const void* qkv, void* ctx, int B, int N, int heads, float scale, void* stream) {
+  if (!qkv || !ctx) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  int r = launch_attn_bf16((const bf16_t*)qkv, (bf16_t*)ctx, B, N, heads, scale, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_attention_bf16 rejected");
+  return DOD_OK;
+}
+int dod_op_attention_f32(const float* q, const float* k, const float* v, float* o, int ldq, int ldk, int ldv, int ldo, int Lq, int Lk,
+                         int B, int heads, int dh, float scale, void* stream) {
+  if (!q || !k || !v || !o) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  AttnF32 a; a.q = q; a.k = k; a.v = v; a.o = o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.Lq = Lq; a.Lk = Lk; a.B = B; a.heads = heads; a.dh = dh; a.scale = scale;
+  int r = launch_attn_f32(a, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_attention_f32 rejected (dh=%d)", dh);
+  return DOD_OK;
+}
+int dod_op_deform_sample(const float* proj, int ldp, const float* values, int B, int Q, int N, int Hd, int P, int dh, int hh, int ww, float* out, void* stream) {
+  if (!proj || !values || !out) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  if (hh * ww != N) return fail(nullptr, DOD_ERR_INVALID, "Cannot reshape input of size %d into a %dx%d feature map", N, hh, ww);
+  int r = launch_deform_sample(proj, ldp, values, B, Q, N, Hd, P, dh, hh, ww, out, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_deform_sample rejected");
+  return DOD_OK;
+}
+int dod_op_pos_resize(const float* pos_in, int G, int gh, int gw, int D, float* pos_out, void* stream) {
+  if (!pos_in || !pos_out) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  return launch_pos_resize(pos_in, G, gh, gw, D, pos_out, (hipStream_t)stream) ? fail(nullptr, DOD_ERR_HIP, "launch failed") : DOD_OK;
+}
+int dod_op_im2col(const float* img, int B, int H, int W, int patch, int Kp, void* out, int out_dtype, void* stream) {
+  if (!img || !out) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  int r = launch_im2col(img, B, H, W, patch, Kp, out_dtype == DOD_F32 ? (float*)out : nullptr, out_dtype == DOD_BF16 ? (bf16_t*)out : nullptr, (hipStream_t)stream);
+  return r ? fail(nullptr, DOD_ERR_INVALID, "dod_op_im2col rejected") : DOD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// Shared device helpers + launcher prototypes for the dino_detector forward path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef unsigned short bf16_t;   // storage type of bf16 in memory
+
+#define DOD_WAVE 64
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;   // v_cvt_pk_bf16_f32: RNE, NaN preserved
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) {
+  return __builtin_bit_cast(float, ((uint32_t)h) << 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// exact-erf GELU (HF ACT2FN["gelu"], modeling_dinov2.py:288-296)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ----------------------------------------------------------------------------- epilogue description
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
+
+// C[m][n] = act( (A W^T)[m][n] + bias[n] ) * scale[n] + resid[m'][n]   (each optional)
+// Output row m' = m unless rows_per_img > 0, in which case (patch-embed, K1/K2 fusion):
+//   b = m / rows_per_img, p = m % rows_per_img, m' = b * out_rows_per_img + 1 + p and pos[(1+p)][n] is added.
+struct GemmEpi {
+  const float* bias;      // [N] or null
+  const float* scale;     // [N] LayerScale lambda or null
+  const float* resid;     // fp32 [M', ldr] or null (may alias out_f32)
+  int ldr;
+  float* out_f32;         // one of out_f32 / out_bf16 non-null
+  bf16_t* out_bf16;
+  int ldc;
+  int act;
+  const float* pos;       // [out_rows_per_img, N] (patch-embed only)
+  int rows_per_img;
+  int out_rows_per_img;
+};
+
+// ----------------------------------------------------------------------------- launchers (all enqueue on `s`, no sync)
+// gemm: C = A[M,K] (row-major, lda) x W[N,K]^T (row-major, ldw)
+int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K,
+                     const GemmEpi& e, hipStream_t s);
+int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K,
+                    const GemmEpi& e, hipStream_t s);
+
+// rows x D LayerNorm, optional pre-add (y = LN(x + add)), fp32 statistics; out bf16 or fp32
+int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
+                     int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s);
+
+// backbone attention, bf16 MFMA flash kernel, head_dim 64.  qkv [B*N, 3*D] bf16 -> ctx [B*N, D] bf16
+int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s);
+
+// generic fp32 attention (strict backbone, decoder self-attn, dense cross-attn). head_dim <= 128, %4 == 0
+struct AttnF32 {
+  const float *q, *k, *v; float* o;
+  int ldq, ldk, ldv, ldo;     // row strides (floats)
+  int Lq, Lk;                 // rows per batch item
+  int B, heads, dh;
+  float scale;
+};
+int launch_attn_f32(const AttnF32& a, hipStream_t s);
+
+// patch im2col: img [B,3,H,W] fp32 -> A [B*gh*gw, Kp] (k = c*p*p + i*p + j, zero padded to Kp)
+int launch_im2col(const float* img, int B, int H, int W, int patch, int Kp, float* out_f32, bf16_t* out_bf16, hipStream_t s);
+// x[b][0][:] = cls + pos[0]
+int launch_cls_row(const float* cls, const float* pos, float* x, int B, int N, int D, hipStream_t s);
+// bicubic resize of the patch position table (torch upsample_bicubic2d, A=-0.75, align_corners=False)
+int launch_pos_resize(const float* pos_in, int G, int gh, int gw, int D, float* pos_out, hipStream_t s);
+// silu(x1)*x2 over [rows, 2*Fh] -> [rows, Fh]
+int launch_swiglu(const float* in_f32, const bf16_t* in_bf16, int rows, int Fh, float* out_f32, bf16_t* out_bf16, hipStream_t s);
+int launch_cast_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+// dst[r][c] (ld_dst) = src[r][c] for a [rows, cols] fp32 block, zero-filling cols..cols_pad
+int launch_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, int cols_pad, hipStream_t s);
+// W' = W + alpha * B[out,r] A[r,in]
+int launch_lora_merge(const float* W, const float* A, const float* Bm, float alpha, int out_f, int in_f, int r, float* dst, hipStream_t s);
+// tgt[b][q][:] = query_embed[q][:]
+int launch_bcast_rows(const float* src, float* dst, int B, int rows, int D, hipStream_t s);
+
+// K12/K13/K15: proj [B*Q, ldp] = [ref logits(2) | offsets(Hd*P*2) | weight logits(Hd*P)], values fp32 [B*N, Dd]
+int launch_deform_sample(const float* proj, int ldp, const float* values, int B, int Q, int N, int Hd, int P, int dh,
+                         int h, int w, float* out, hipStream_t s);

@@ -1,0 +1,243 @@
+// Row-wise / elementwise kernels of the forward path: LayerNorm (K3, K17/K18 post-norms), patch im2col
+// (K1 front end), CLS row (K2), bicubic position-table resize (K2), SwiGLU gate (K7g) and the
+// one-time weight packing helpers (LoRA merge K8, casts, concatenation).  All HBM-bound:
+// wave-per-row with 16-byte accesses, fp32 statistics, shuffle reductions.
+#include "dod_common.h"
+
+// ----------------------------------------------------------------------------- LayerNorm
+// nn.LayerNorm over the last dim (modeling_dinov2.py:348,353,441 eps 1e-6; deformable_attention.py:197-209
+// eps 1e-5).  One wave per row, D % 4 == 0, D <= 2048.  Two-pass statistics in registers
+// (mean, then centred variance) like ATen's RowwiseMoments result to fp32 rounding.
+#define LN_MAXC 8
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int rows, int D, float* __restrict__ out_f32,
+                                                        bf16_t* __restrict__ out_bf16) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nc = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+  const float4* ar = add ? reinterpret_cast<const float4*>(add + (size_t)row * D) : nullptr;
+  float4 v[LN_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nc) {
+      v[i] = xr[c];
+      if (ar) { const float4 a = ar[c]; v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w; }
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nc) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nc) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+      const float4 b = reinterpret_cast<const float4*>(beta)[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[c] = o;
+      if (out_bf16) {
+        uint2 p;
+        p.x = pack2bf(o.x, o.y);
+        p.y = pack2bf(o.z, o.w);
+        reinterpret_cast<uint2*>(out_bf16 + (size_t)row * D)[c] = p;
+      }
+    }
+  }
+}
+
+int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
+                     int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s) {
+  if (rows <= 0) return 1;
+  if (D % 4 != 0 || D > 256 * LN_MAXC) return 2;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, add, gamma, beta, eps, rows, D,
+                     out_f32, out_bf16);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// ----------------------------------------------------------------------------- im2col for Conv2d(3->D, k=p, s=p)
+// A[m][k]: m = b*gh*gw + py*gw + px, k = c*p*p + i*p + j  (weight.reshape(D, 3*p*p) order,
+// modeling_dinov2.py:139,148).  Thread per output element; consecutive k within an (c,i) run read
+// consecutive pixels.  Columns k >= 3*p*p are zero (K padding for the bf16 kernel's BK).
+__global__ void im2col_kernel(const float* __restrict__ img, int B, int H, int W, int p, int gh, int gw, int Kp,
+                              float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16) {
+  const size_t total = (size_t)B * gh * gw * Kp;
+  const int K = 3 * p * p;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % Kp);
+    const size_t m = idx / Kp;
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / (p * p), r = k - c * p * p, i = r / p, j = r - i * p;
+      const int px = (int)(m % gw);
+      const size_t t = m / gw;
+      const int py = (int)(t % gh);
+      const int b = (int)(t / gh);
+      v = img[(((size_t)b * 3 + c) * H + (py * p + i)) * W + (px * p + j)];
+    }
+    if (out_f32) out_f32[idx] = v; else out_bf16[idx] = f2bf(v);
+  }
+}
+
+int launch_im2col(const float* img, int B, int H, int W, int patch, int Kp, float* out_f32, bf16_t* out_bf16, hipStream_t s) {
+  const int gh = H / patch, gw = W / patch;
+  if (B <= 0 || gh <= 0 || gw <= 0 || Kp < 3 * patch * patch) return 2;
+  const size_t total = (size_t)B * gh * gw * Kp;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, s, img, B, H, W, patch, gh, gw, Kp, out_f32, out_bf16);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// ----------------------------------------------------------------------------- CLS row: x[b][0][:] = cls + pos[0]
+__global__ void cls_row_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x,
+                               int B, int N, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  x[(size_t)b * N * D + d] = cls[d] + pos[d];
+}
+int launch_cls_row(const float* cls, const float* pos, float* x, int B, int N, int D, hipStream_t s) {
+  hipLaunchKernelGGL(cls_row_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, cls, pos, x, B, N, D);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// ----------------------------------------------------------------------------- bicubic position-table resize
+// Dinov2Embeddings.interpolate_pos_encoding (modeling_dinov2.py:57-95): the G x G patch position
+// table is resized to gh x gw with F.interpolate(mode="bicubic", align_corners=False) in fp32; row 0
+// (class position) is copied.  Restates ATen upsample_bicubic2d: scale = in/out, src = scale*(dst+0.5)-0.5
+// (not clamped), A = -0.75, taps at floor(src)-1..+2 clamped to the border, x-interpolation first.
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__global__ void pos_resize_kernel(const float* __restrict__ pin, int G, int gh, int gw, int D, float* __restrict__ pout) {
+  const size_t total = (size_t)(gh * gw + 1) * D;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int d = (int)(idx % D);
+  const int tok = (int)(idx / D);
+  if (tok == 0) { pout[idx] = pin[d]; return; }
+  const int oy = (tok - 1) / gw, ox = (tok - 1) - oy * gw;
+  const float A = -0.75f;
+  const float sy = (float)G / (float)gh, sx = (float)G / (float)gw;
+  const float ry = sy * ((float)oy + 0.5f) - 0.5f, rx = sx * ((float)ox + 0.5f) - 0.5f;
+  const float fy = floorf(ry), fx = floorf(rx);
+  const int iy = (int)fy, ix = (int)fx;
+  const float ty = ry - fy, tx = rx - fx;
+  const float cy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+  const float cx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    int yy = iy - 1 + a; yy = yy < 0 ? 0 : (yy > G - 1 ? G - 1 : yy);
+    float rowv = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int xx = ix - 1 + b; xx = xx < 0 ? 0 : (xx > G - 1 ? G - 1 : xx);
+      rowv += pin[(size_t)(1 + yy * G + xx) * D + d] * cx[b];
+    }
+    acc += rowv * cy[a];
+  }
+  pout[idx] = acc;
+}
+int launch_pos_resize(const float* pos_in, int G, int gh, int gw, int D, float* pos_out, hipStream_t s) {
+  const size_t total = (size_t)(gh * gw + 1) * D;
+  hipLaunchKernelGGL(pos_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pos_in, G, gh, gw, D, pos_out);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// ----------------------------------------------------------------------------- SwiGLU gate (giant): silu(x1) * x2
+// Dinov2SwiGLUFFN.forward, modeling_dinov2.py:310-314: x1, x2 = chunk(2, dim=-1)
+__global__ void swiglu_kernel(const float* __restrict__ in_f32, const bf16_t* __restrict__ in_bf16, int rows, int Fh,
+                              float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16) {
+  const size_t total = (size_t)rows * Fh;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = idx / Fh;
+    const int c = (int)(idx - r * Fh);
+    float a, b;
+    if (in_f32) { a = in_f32[r * 2 * Fh + c]; b = in_f32[r * 2 * Fh + Fh + c]; }
+    else { a = bf2f(in_bf16[r * 2 * Fh + c]); b = bf2f(in_bf16[r * 2 * Fh + Fh + c]); }
+    const float v = a / (1.0f + expf(-a)) * b;
+    if (out_f32) out_f32[idx] = v; else out_bf16[idx] = f2bf(v);
+  }
+}
+int launch_swiglu(const float* in_f32, const bf16_t* in_bf16, int rows, int Fh, float* out_f32, bf16_t* out_bf16, hipStream_t s) {
+  const size_t total = (size_t)rows * Fh;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(swiglu_kernel, dim3(blocks), dim3(256), 0, s, in_f32, in_bf16, rows, Fh, out_f32, out_bf16);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// ----------------------------------------------------------------------------- packing helpers (one-time, at finalize)
+__global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
+}
+int launch_cast_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, s, in, out, n);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+__global__ void copy2d_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, int rows,
+                              int cols, int cols_pad) {
+  const size_t total = (size_t)rows * cols_pad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / cols_pad;
+    const int c = (int)(i - r * cols_pad);
+    dst[r * ld_dst + c] = c < cols ? src[r * ld_src + c] : 0.f;
+  }
+}
+int launch_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, int cols_pad, hipStream_t s) {
+  const size_t total = (size_t)rows * cols_pad;
+  if (total == 0) return 0;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(copy2d_kernel, dim3(blocks), dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols, cols_pad);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// LoraLinear (dino_detector/utils.py:68-70): linear(x) + alpha * lora_B(lora_A(x))  ==  x (W + alpha B A)^T + b.
+// fp32 merge, summed over r in index order.
+__global__ void lora_merge_kernel(const float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ Bm,
+                                  float alpha, int out_f, int in_f, int r, float* __restrict__ dst) {
+  const size_t total = (size_t)out_f * in_f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = i / in_f;
+    const int c = (int)(i - o * in_f);
+    float acc = 0.f;
+    for (int t = 0; t < r; ++t) acc += Bm[o * r + t] * A[(size_t)t * in_f + c];
+    dst[i] = W[i] + alpha * acc;
+  }
+}
+int launch_lora_merge(const float* W, const float* A, const float* Bm, float alpha, int out_f, int in_f, int r, float* dst, hipStream_t s) {
+  const size_t total = (size_t)out_f * in_f;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(lora_merge_kernel, dim3(blocks), dim3(256), 0, s, W, A, Bm, alpha, out_f, in_f, r, dst);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// tgt = query_embed.weight.unsqueeze(0).repeat(B,1,1)   detr_decoder.py:59
+__global__ void bcast_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, size_t n) {
+  const size_t total = (size_t)B * n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i % n];
+}
+int launch_bcast_rows(const float* src, float* dst, int B, int rows, int D, hipStream_t s) {
+  const size_t n = (size_t)rows * D, total = n * B;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3(blocks), dim3(256), 0, s, src, dst, B, n);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}

@@ -1,0 +1,157 @@
+"""Host-side engine: owns a dod_handle, pushes the module's parameters across the C ABI,
+keeps a workspace tensor, and launches the forward on torch's current HIP stream.
+
+The engine is the only place that touches libdinodet.so; torch provides device memory and the
+stream, nothing else.  No CPU path exists: a non-GPU tensor raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _native as nat
+from .config import BackboneConfig, DecoderConfig
+
+
+def default_precision():
+    return os.environ.get("DINODET_PRECISION", "bf16")
+
+
+def make_config(bb: BackboneConfig, dc: DecoderConfig, precision: str) -> nat.DodConfig:
+    if precision not in nat.PREC:
+        raise ValueError(f"precision must be one of {sorted(nat.PREC)}, got {precision!r}")
+    c = nat.DodConfig()
+    c.hidden, c.layers, c.heads, c.swiglu = bb.hidden, bb.layers, bb.heads, int(bb.swiglu)
+    c.patch, c.pos_grid, c.ffn_hidden, c.ln_eps = bb.patch, bb.pos_grid, bb.ffn_hidden, bb.ln_eps
+    c.lora_r, c.lora_alpha, c.target_dim = bb.lora_r, bb.lora_alpha, bb.target_dim
+    c.num_queries, c.dec_hidden, c.dec_heads, c.dec_layers = dc.num_queries, dc.hidden_dim, dc.nheads, dc.num_layers
+    c.num_classes, c.dim_feedforward, c.n_points = dc.num_classes, dc.dim_feedforward, dc.n_points
+    c.use_deformable, c.dec_ln_eps = int(dc.use_deformable), dc.ln_eps
+    c.precision = nat.PREC[precision]
+    return c
+
+
+class Engine:
+    def __init__(self, bb: BackboneConfig, dc: DecoderConfig, precision: str):
+        self.bb, self.dc, self.precision = bb, dc, precision
+        self._lib = nat.lib()
+        self._h = C.c_void_p()
+        cfg = make_config(bb, dc, precision)
+        nat.check(self._lib.dod_create(C.byref(cfg), C.byref(self._h)))
+        self._sig = None
+        self._ws = None
+        self._keep = []     # tensors whose pointers the handle holds until finalize returns
+        self._tap_bufs = {}
+
+    def close(self):
+        if self._h:
+            self._lib.dod_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    @staticmethod
+    def signature(named):
+        return tuple((k, t.data_ptr(), t._version, tuple(t.shape)) for k, t in named)
+
+    def sync_weights(self, named):
+        """named: list of (reference state-dict key, fp32 CUDA tensor).  Re-packs only when a
+        tensor moved or was modified in place (load_state_dict, optimizer step, .to())."""
+        sig = self.signature(named)
+        if sig == self._sig:
+            return
+        self._keep = []
+        for k, t in named:
+            if not t.is_cuda:
+                raise RuntimeError(f"parameter {k} is on {t.device}: the MI355X path has no CPU fallback")
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.detach().to(torch.float32).contiguous()
+                self._keep.append(t)
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            nat.check(self._lib.dod_set_weight(self._h, k.encode(), nat.ptr(t), shape, t.dim()), self._h)
+        nat.check(self._lib.dod_finalize_weights(self._h, nat.stream_ptr()), self._h)
+        self._keep = []
+        self._sig = sig
+        self._ws = None
+
+    # ------------------------------------------------------------------ forward
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    @staticmethod
+    def _check_pixels(x):
+        if x.dim() != 4:
+            raise ValueError(f"pixel_values must be [batch, 3, H, W], got shape {tuple(x.shape)}")
+        if x.shape[1] != 3:
+            # same message as Dinov2PatchEmbeddings.forward (modeling_dinov2.py:143-147)
+            raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in "
+                             f"the configuration. Expected 3 but got {x.shape[1]}.")
+        if not x.is_cuda:
+            raise RuntimeError("pixel_values must be on the GPU: the MI355X path has no CPU fallback")
+        return x.detach().to(torch.float32).contiguous()
+
+    def forward(self, pixel_values, named):
+        x = self._check_pixels(pixel_values)
+        self.sync_weights(named)
+        B, _, H, W = x.shape
+        nbytes = self._lib.dod_workspace_bytes(self._h, B, H, W)
+        if nbytes == 0:
+            raise ValueError(f"unsupported input {tuple(x.shape)}")
+        ws = self._workspace(nbytes, x.device)
+        det = torch.empty(B, self.dc.num_queries, self.dc.num_classes + 4, dtype=torch.float32, device=x.device)
+        nat.check(self._lib.dod_forward(self._h, nat.ptr(x), B, H, W, nat.ptr(det), nat.ptr(ws), ws.numel(),
+                                        nat.stream_ptr()), self._h)
+        return det
+
+    def backbone_forward(self, pixel_values, named):
+        x = self._check_pixels(pixel_values)
+        self.sync_weights(named)
+        B, _, H, W = x.shape
+        nbytes = self._lib.dod_workspace_bytes(self._h, B, H, W)
+        if nbytes == 0:
+            raise ValueError(f"unsupported input {tuple(x.shape)}")
+        ws = self._workspace(nbytes, x.device)
+        N = self._lib.dod_num_tokens(self._h, H, W)
+        feats = torch.empty(B, N, self.bb.out_dim, dtype=torch.float32, device=x.device)
+        nat.check(self._lib.dod_backbone_forward(self._h, nat.ptr(x), B, H, W, nat.ptr(feats), nat.ptr(ws),
+                                                 ws.numel(), nat.stream_ptr()), self._h)
+        return feats
+
+    def decoder_forward(self, memory, named):
+        if memory.dim() != 3 or memory.shape[-1] != self.dc.hidden_dim:
+            raise ValueError(f"src must be [batch, seq_len, {self.dc.hidden_dim}], got {tuple(memory.shape)}")
+        if not memory.is_cuda:
+            raise RuntimeError("src must be on the GPU: the MI355X path has no CPU fallback")
+        m = memory.detach().to(torch.float32).contiguous()
+        self.sync_weights(named)
+        B, N, _ = m.shape
+        nbytes = self._lib.dod_decoder_workspace_bytes(self._h, B, N)
+        ws = self._workspace(nbytes, m.device)
+        det = torch.empty(B, self.dc.num_queries, self.dc.num_classes + 4, dtype=torch.float32, device=m.device)
+        nat.check(self._lib.dod_decoder_forward(self._h, nat.ptr(m), B, N, nat.ptr(det), nat.ptr(ws), ws.numel(),
+                                                nat.stream_ptr()), self._h)
+        return det
+
+    # ------------------------------------------------------------------ debug taps (parity tests)
+    def set_tap(self, stage, shape, device):
+        buf = torch.zeros(*shape, dtype=torch.float32, device=device)
+        self._tap_bufs[stage] = buf
+        nat.check(self._lib.dod_set_tap(self._h, stage, nat.ptr(buf)), self._h)
+        return buf
+
+    def clear_taps(self):
+        for st in list(self._tap_bufs):
+            nat.check(self._lib.dod_set_tap(self._h, st, C.c_void_p(0)), self._h)
+        self._tap_bufs = {}
+
+
+def split_detections(det, num_classes):
+    """packed [B,Q,C+4] -> the reference's output dict (detr_decoder.py:83): zero-copy views."""
+    return {"pred_logits": det[..., :num_classes], "pred_boxes": det[..., num_classes:]}

@@ -1,0 +1,59 @@
+"""DINOv2ObjectDetector: host-side mirror of dino_detector/models/detector.py:8-69."""
+import torch.nn as nn
+
+from ..config import REF_DEFAULTS
+from ..engine import default_precision, split_detections
+from .dinov2_backbone import DINOv2Backbone, _EngineMixin
+from .detr_decoder import DETRDecoder
+
+
+class DINOv2ObjectDetector(nn.Module, _EngineMixin):
+    """Same constructor defaults as the reference (config.py:21-35 via detector.py:9-21).
+    Extra keyword arguments: `pretrained`, `precision`, `backbone_config` (micro test models)."""
+
+    def __init__(self,
+                 num_classes=REF_DEFAULTS["num_classes"],
+                 dino_model_name=REF_DEFAULTS["dino_model_name"],
+                 lora_r=REF_DEFAULTS["lora_r"],
+                 lora_alpha=REF_DEFAULTS["lora_alpha"],
+                 hidden_dim=REF_DEFAULTS["hidden_dim"],
+                 num_queries=REF_DEFAULTS["num_queries"],
+                 nheads=REF_DEFAULTS["nheads"],
+                 num_decoder_layers=REF_DEFAULTS["num_decoder_layers"],
+                 dim_feedforward=REF_DEFAULTS["dim_feedforward"],
+                 dropout=REF_DEFAULTS["dropout"],
+                 n_points=REF_DEFAULTS["n_points"],
+                 use_deformable=REF_DEFAULTS["use_deformable"],
+                 pretrained=True, precision=None, backbone_config=None):
+        super().__init__()
+        if hidden_dim is None:                                  # detector.py:25-35
+            hidden_dim = 768
+            for key, dim in (("small", 384), ("base", 768), ("large", 1024), ("giant", 1536)):
+                if key in dino_model_name:
+                    hidden_dim = dim
+                    break
+        precision = precision or default_precision()
+        self.backbone = DINOv2Backbone(model_name=dino_model_name, lora_r=lora_r, lora_alpha=lora_alpha,
+                                       target_dim=hidden_dim, pretrained=pretrained, precision=precision,
+                                       config=backbone_config)
+        self.decoder = DETRDecoder(num_queries=num_queries, hidden_dim=hidden_dim, nheads=nheads,
+                                   num_decoder_layers=num_decoder_layers, num_classes=num_classes,
+                                   dim_feedforward=dim_feedforward, dropout=dropout, n_points=n_points,
+                                   use_deformable=use_deformable, precision=precision)
+        self.precision = precision
+        self._dropout_p = float(dropout)
+        self._bb_cfg = self.backbone._bb_cfg
+        self._dc_cfg = self.decoder._dc_cfg
+
+    def _engine_named(self):
+        return list(self.state_dict(keep_vars=True).items())    # keys already "backbone." / "decoder."
+
+    def forward_packed(self, pixel_values):
+        """[B,3,H,W] -> packed detections [B, Q, C+4] (logits | boxes): the buffer the multi-GPU
+        all-gather moves (dinov2_od_amd.dist.gather_detections)."""
+        self._check_mode()
+        return self._get_engine().forward(pixel_values, self._engine_named())
+
+    def forward(self, pixel_values):
+        """pixel_values [batch, 3, H, W] -> {"pred_logits", "pred_boxes"} (detector.py:58-69)."""
+        return split_detections(self.forward_packed(pixel_values), self._dc_cfg.num_classes)

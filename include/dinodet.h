@@ -1,0 +1,147 @@
+/* dinodet.h -- C ABI of the MI355X-native dino_detector forward path (libdinodet.so).
+ *
+ * The reference (mudit1729/dinov2-od) is pure Python and has no FFI of its own; this ABI is the
+ * boundary SURVEY.md section 8b defines for the path
+ *     DINOv2ObjectDetector.forward   dino_detector/models/detector.py:58-69
+ *       DINOv2Backbone.forward       dino_detector/models/dinov2_backbone.py:58-67
+ *       DETRDecoder.forward          dino_detector/models/detr_decoder.py:47-83
+ * and is what the reference-side binding (a ctypes stub) calls.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every tensor pointer is a DEVICE pointer (HIP), row-major, fp32
+ *    unless stated; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - every call returns 0 on success, a non-zero dod_status otherwise; no C++ exception crosses
+ *    the ABI.  dod_last_error() returns a message for the last failing call on that handle
+ *    (handle may be NULL for errors of dod_create / stateless ops).
+ *  - all work is enqueued on the caller's stream; forward calls never synchronise and never
+ *    allocate once dod_prepare() has been called for that (H, W).
+ *  - a handle is re-entrant across handles but not thread-safe on one handle (the reference is
+ *    one Python thread per process, one process per GPU: train.py:1501-1506).
+ *  - ownership: I/O buffers, the workspace and the weight tensors passed to dod_set_weight are
+ *    caller-owned; weights are only read during dod_finalize_weights(), which builds the handle's
+ *    private packed copy (LoRA merged, QKV concatenated, bf16 casts).
+ */
+#ifndef DINODET_H
+#define DINODET_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dod_handle dod_handle;
+
+enum dod_status {
+  DOD_OK = 0,
+  DOD_ERR_INVALID = 1,      /* bad argument / unsupported shape  (Python raises ValueError)   */
+  DOD_ERR_MISSING = 2,      /* a required state-dict key was never set (KeyError)             */
+  DOD_ERR_STATE = 3,        /* call order: not finalized, workspace too small (RuntimeError)  */
+  DOD_ERR_HIP = 4           /* HIP runtime error (RuntimeError)                               */
+};
+
+enum dod_precision {
+  DOD_PREC_FP32 = 0,        /* exact-fp32 MFMA/VALU everywhere: the mode gated at 1e-3 parity  */
+  DOD_PREC_BF16 = 1         /* bf16 MFMA operands in the backbone + value projection, fp32
+                               accumulate / residual stream / LayerNorm / softmax / decoder     */
+};
+
+/* Shapes.  Backbone fields mirror HF Dinov2Config as used by dinov2_backbone.py:11-27; decoder
+ * fields mirror the DETRDecoder constructor (detr_decoder.py:8-9) / config.py:21-35. */
+typedef struct dod_config {
+  int32_t hidden;           /* D: 384 / 768 / 1024 / 1536 */
+  int32_t layers;
+  int32_t heads;            /* head_dim must be 64 in bf16 mode */
+  int32_t swiglu;           /* 1 for giant (Dinov2SwiGLUFFN) */
+  int32_t patch;            /* 14 */
+  int32_t pos_grid;         /* 37: pretrained position grid side */
+  int32_t ffn_hidden;       /* 4*D, or the SwiGLU hidden size (4096 for giant) */
+  float   ln_eps;           /* 1e-6 */
+  int32_t lora_r;           /* informational; LoRA presence is detected per linear from the keys */
+  float   lora_alpha;
+  int32_t target_dim;       /* 0 = no projection (dinov2_backbone.py:33-37) */
+  int32_t num_queries;
+  int32_t dec_hidden;       /* Dd */
+  int32_t dec_heads;
+  int32_t dec_layers;
+  int32_t num_classes;
+  int32_t dim_feedforward;
+  int32_t n_points;
+  int32_t use_deformable;
+  float   dec_ln_eps;       /* 1e-5 */
+  int32_t precision;        /* dod_precision */
+} dod_config;
+
+int dod_create(const dod_config* cfg, dod_handle** out);
+void dod_destroy(dod_handle* h);
+const char* dod_last_error(const dod_handle* h);
+
+/* Register one fp32 device tensor under its reference state-dict key
+ * (e.g. "backbone.dino.encoder.layer.3.attention.attention.query.weight",
+ *  "...layer.11.mlp.fc1.lora_A.weight", "decoder.decoder.layers.0.cross_attn.value_proj.bias").
+ * A leading "module." (DDP, train.py:700-709) is ignored.  Unknown keys are accepted and unused. */
+int dod_set_weight(dod_handle* h, const char* key, const void* dev_ptr, const int64_t* shape, int ndim);
+
+/* Build the packed weights (merges W + alpha*B*A, concatenates q/k/v, casts).  Synchronises `stream`
+ * once at the end; after it returns the caller's weight tensors are no longer referenced.
+ * May be called again after new dod_set_weight calls (e.g. after load_state_dict / an optimizer step). */
+int dod_finalize_weights(dod_handle* h, void* stream);
+
+/* Precompute (and cache in the handle) the position table for an H x W input -- bicubic resize of the
+ * pretrained grid when (H/patch, W/patch) != (pos_grid, pos_grid), modeling_dinov2.py:57-95.
+ * Forward calls do this lazily; call it first when the forward is to be captured in a hipGraph. */
+int dod_prepare(dod_handle* h, int H, int W, void* stream);
+
+/* Bytes of scratch a forward of batch B at H x W needs. 0 on error. */
+size_t dod_workspace_bytes(const dod_handle* h, int B, int H, int W);
+int dod_num_tokens(const dod_handle* h, int H, int W);     /* N = (H/p)*(W/p) + 1 */
+
+/* DINOv2ObjectDetector.forward: pixels [B,3,H,W] -> detections [B, Q, C+4] packed
+ * (columns 0..C-1 = pred_logits, C..C+3 = pred_boxes cx,cy,w,h after sigmoid). */
+int dod_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* detections,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* DINOv2Backbone.forward: pixels -> features [B, N, out_dim] fp32 (CLS token at index 0). */
+int dod_backbone_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* features,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* DETRDecoder.forward: memory [B, N, Dd] fp32 -> detections [B, Q, C+4] packed. */
+int dod_decoder_forward(dod_handle* h, const float* memory, int B, int N, float* detections,
+                        void* workspace, size_t workspace_bytes, void* stream);
+size_t dod_decoder_workspace_bytes(const dod_handle* h, int B, int N);
+
+/* Debug taps: if set, the next forwards copy that stage (fp32) into `dst` (caller-sized).
+ * stage: 0 = embeddings [B,N,D]; 1+i = output of encoder block i [B,N,D]; 1000 = decoder memory
+ * [B,N,Dd] (final LayerNorm / projection); 2000 = value projection [B,N,Dd]; 3000+j = decoder layer j
+ * output [B,Q,Dd].  dst = NULL clears the tap. */
+int dod_set_tap(dod_handle* h, int stage, float* dst);
+
+/* ---- stateless operator entry points (the same kernels the forward uses; for parity tests) ------ */
+enum dod_dtype { DOD_F32 = 0, DOD_BF16 = 1 };
+enum dod_act { DOD_ACT_NONE = 0, DOD_ACT_RELU = 1, DOD_ACT_GELU = 2, DOD_ACT_SIGMOID = 3 };
+
+/* out[M,N] = act(A[M,K] W[N,K]^T + bias) * scale + resid ; A, W of dtype `in_dtype`; bias/scale/resid fp32 or NULL */
+int dod_op_linear(int in_dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
+                  const float* bias, const float* scale, const float* resid, int ldr,
+                  void* out, int out_dtype, int ldc, int act, void* stream);
+/* out = LayerNorm(x + add) ; add may be NULL */
+int dod_op_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
+                     int rows, int D, void* out, int out_dtype, void* stream);
+/* qkv [B*N, 3*heads*64] bf16 -> ctx [B*N, heads*64] bf16 */
+int dod_op_attention_bf16(const void* qkv, void* ctx, int B, int N, int heads, float scale, void* stream);
+int dod_op_attention_f32(const float* q, const float* k, const float* v, float* o, int ldq, int ldk, int ldv,
+                         int ldo, int Lq, int Lk, int B, int heads, int dh, float scale, void* stream);
+/* proj [B*Q, ldp] = [ref logits(2) | offsets(Hd*P*2) | weight logits(Hd*P)], values [B*N, Hd*dh] -> out [B*Q, Hd*dh] */
+int dod_op_deform_sample(const float* proj, int ldp, const float* values, int B, int Q, int N, int Hd, int P,
+                         int dh, int h, int w, float* out, void* stream);
+/* pos_in [G*G+1, D] -> pos_out [gh*gw+1, D] */
+int dod_op_pos_resize(const float* pos_in, int G, int gh, int gw, int D, float* pos_out, void* stream);
+/* img [B,3,H,W] -> cols [B*(H/p)*(W/p), Kp] of out_dtype */
+int dod_op_im2col(const float* img, int B, int H, int W, int patch, int Kp, void* out, int out_dtype, void* stream);
+
+const char* dod_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,192 @@
+"""`-m gpu`: the whole hot path through the drop-in modules / C ABI.
+
+fp32 ("strict") mode is the mode gated at the north-star tolerance: logits and boxes within 1e-3
+relative (max|a-b| / max|b|) of the REFERENCE's own fp32 CPU forward (committed golden vectors) and of
+the CPU oracle, stage by stage.
+bf16 mode (the throughput mode) cannot meet 1e-3 on logits by construction (8-bit mantissa operands;
+DESIGN.md "precision modes"): it is held to the oracle evaluated with the same bf16 operand rounding,
+and its distance to the fp32 reference is bounded and reported."""
+import numpy as np
+import pytest
+import torch
+
+from dinov2_od_amd import synth
+from dinov2_od_amd.config import num_tokens
+from oracle import dinodet_oracle as orc
+from tests import cases
+from tests.cases import rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3      # BASELINE.json north_star: "within 1e-3 relative fp32 tolerance (box coords and class logits)"
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from tests import gpu_util
+    return gpu_util
+
+
+def _taps(m, B, N, bb, dc):
+    eng = m._get_engine()
+    t = {"emb": eng.set_tap(0, (B, N, bb.hidden), "cuda:0")}
+    for i in range(bb.layers):
+        t[f"block{i}"] = eng.set_tap(1 + i, (B, N, bb.hidden), "cuda:0")
+    t["mem"] = eng.set_tap(1000, (B, N, dc.hidden_dim), "cuda:0")
+    for j in range(dc.num_layers):
+        t[f"dec{j}"] = eng.set_tap(3000 + j, (B, dc.num_queries, dc.hidden_dim), "cuda:0")
+    return t
+
+
+@pytest.mark.parametrize("swiglu", [False, True])
+@pytest.mark.parametrize("R", [70, 56])
+def test_strict_micro_backbone_every_stage_vs_reference(G, swiglu, R):
+    """G0/G4 goldens: embeddings (incl. bicubic 5->4 at 56x56), each block, final features."""
+    from dinov2_od_amd.models import DINOv2Backbone
+    g = cases.golden("g4_micro_swiglu" if swiglu else "g0_micro_backbone")
+    bb = cases.micro_bb(swiglu)
+    m = DINOv2Backbone("micro", lora_r=2, lora_alpha=1.0, target_dim=None, pretrained=False, precision="fp32", config=bb)
+    G.load_np_state(m, synth.backbone_state_dict(bb, seed=1, prefix=""))
+    m = m.to(G.dev()).eval()
+    x = G.to_gpu(synth.make_pixels(2, R, R, seed=0))
+    N = num_tokens(R, R)
+    eng = m._get_engine()
+    emb = eng.set_tap(0, (2, N, bb.hidden), "cuda:0")
+    blocks = [eng.set_tap(1 + i, (2, N, bb.hidden), "cuda:0") for i in range(bb.layers)]
+    f = m(x)
+    G.sync()
+    assert rel_err(emb.cpu().numpy(), g[f"embeddings_{R}"]) < 1e-5
+    for i, b in enumerate(blocks):
+        assert rel_err(b.cpu().numpy(), g[f"block{i}_{R}"]) < 1e-5, i
+    assert rel_err(f.cpu().numpy(), g[f"features_{R}"]) < 1e-5
+
+
+@pytest.mark.parametrize("case", cases.G1_CASES, ids=[c[0] for c in cases.G1_CASES])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_decoder_only_vs_reference(G, case, precision):
+    """G1 goldens: DETRDecoder on random memory, deformable and dense branches, head dims 32 and 96,
+    N in {17, 26, 257, 1370} (pins the (h,w) factorisation quirk)."""
+    from dinov2_od_amd.models import DETRDecoder
+    tag, deform, Dd, Hd, Q, Ns = case
+    g = cases.golden("g1_decoder_only")
+    dc = cases.dec_cfg(deform, Dd, Hd, Q)
+    m = DETRDecoder(Q, Dd, Hd, dc.num_layers, dc.num_classes, dim_feedforward=dc.dim_feedforward, n_points=dc.n_points,
+                    use_deformable=deform, precision=precision)
+    G.load_np_state(m, synth.decoder_state_dict(dc, seed=1, prefix=""))
+    m = m.to(G.dev()).eval()
+    for N in Ns:
+        out = m(G.to_gpu(cases.g1_memory(N, Dd)))
+        G.sync()
+        # bf16 mode rounds the memory and value_proj/kv weights to bf16 -> bounded, looser
+        tol = TOL if precision == "fp32" else 3e-2
+        assert rel_err(out["pred_logits"].cpu().numpy(), g[f"{tag}_N{N}_logits"]) < tol, (tag, N)
+        assert rel_err(out["pred_boxes"].cpu().numpy(), g[f"{tag}_N{N}_boxes"]) < tol, (tag, N)
+
+
+@pytest.mark.parametrize("Q", [25, 100])
+def test_strict_cfg1_end_to_end_vs_reference(G, Q):
+    """BASELINE.json configs[0]: --lightweight ViT-S/14 224x224, batch 2."""
+    g = cases.golden(f"g2_cfg1_q{Q}")
+    bb, dc = cases.cfg1(Q)
+    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-small")
+    out = m(G.to_gpu(synth.make_pixels(2, 224, 224, seed=0)))
+    G.sync()
+    assert out["pred_logits"].shape == (2, Q, 91) and out["pred_boxes"].shape == (2, Q, 4)
+    assert rel_err(out["pred_logits"].cpu().numpy(), g["pred_logits"]) < TOL
+    assert rel_err(out["pred_boxes"].cpu().numpy(), g["pred_boxes"]) < TOL
+
+
+@pytest.mark.parametrize("name,R,deform", [("g3_vitb_224", 224, True), ("g3_vitb_518", 518, True), ("g3_vitb_224_dense", 224, False)])
+def test_strict_vitb_end_to_end_vs_reference(G, name, R, deform):
+    """ViT-B/14 at 224 (bicubic pos resize, (h,w)=(1,257)) and 518 (N=1370, (10,137)); Q=100."""
+    g = cases.golden(name)
+    bb, dc = cases.vitb(100, deform)
+    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-base")
+    x = synth.make_pixels(1, R, R, seed=0)
+    N = num_tokens(R, R)
+    eng = m._get_engine()
+    mem = eng.set_tap(1000, (1, N, 768), "cuda:0")
+    out = m(G.to_gpu(x))
+    G.sync()
+    f = mem.cpu().numpy()
+    assert rel_err(f[:, ::max(1, N // 8), :64], g["feat_probe"]) < 1e-4
+    assert rel_err(out["pred_logits"].cpu().numpy(), g["pred_logits"]) < TOL
+    assert rel_err(out["pred_boxes"].cpu().numpy(), g["pred_boxes"]) < TOL
+
+
+def test_strict_batch_is_independent_and_deterministic(G):
+    """Images are independent (no cross-image op): batch of 3 == three batches of 1, bit for bit;
+    two runs agree bit for bit (no atomics in the path)."""
+    bb, dc = cases.cfg1(25)
+    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-small")
+    x = G.to_gpu(synth.make_pixels(3, 224, 224, seed=0))
+    a = m.forward_packed(x).clone()
+    b = m.forward_packed(x).clone()
+    assert torch.equal(a, b)
+    for i in range(3):
+        one = m.forward_packed(x[i:i + 1])
+        assert torch.equal(one[0], a[i]), i
+
+
+@pytest.mark.parametrize("R,B", [(224, 2), (518, 1)])
+def test_bf16_vitb_vs_bf16_faithful_oracle_and_fp32_reference(G, R, B):
+    """Throughput mode.  Stage-level: decoder memory (final LN) against the oracle evaluated with the
+    same bf16 operand rounding (kernel correctness, tight) and against the fp32 reference (precision
+    cost of bf16, bounded).  Outputs: bounded distance to the fp32 reference, reported in DESIGN.md."""
+    bb, dc = cases.vitb(100, True)
+    sd = synth.detector_state_dict(bb, dc, seed=1)
+    x = synth.make_pixels(B, R, R, seed=0)
+    N = num_tokens(R, R)
+    m = G.make_detector(bb, dc, "bf16", "facebook/dinov2-base")
+    eng = m._get_engine()
+    mem = eng.set_tap(1000, (B, N, 768), "cuda:0")
+    out = m(G.to_gpu(x))
+    G.sync()
+    emu = orc.detector_forward(sd, bb, dc, x, emulate_bf16=True)
+    f32 = orc.detector_forward(sd, bb, dc, x)
+    f = mem.cpu().numpy()
+    e_emu = rel_l2(f, emu["features"].numpy())
+    e_f32 = rel_l2(f, f32["features"].numpy())
+    print(f"bf16 features R={R}: rel-L2 vs bf16-faithful oracle {e_emu:.2e}, vs fp32 oracle {e_f32:.2e}")
+    assert e_emu < 2e-3          # same rounding points; differs by accumulation order + flash-vs-global-max P rounding
+    assert e_f32 < 8e-3          # the cost of 8-bit mantissas through 12 blocks
+    el, eb = rel_l2(out["pred_logits"].cpu().numpy(), f32["pred_logits"].numpy()), rel_l2(out["pred_boxes"].cpu().numpy(), f32["pred_boxes"].numpy())
+    print(f"bf16 outputs R={R}: rel-L2 logits {el:.2e} boxes {eb:.2e} vs fp32 oracle")
+    assert el < 8e-2 and eb < 3e-2
+
+
+def test_bf16_cfg1_end_to_end(G):
+    g = cases.golden("g2_cfg1_q100")
+    bb, dc = cases.cfg1(100)
+    m = G.make_detector(bb, dc, "bf16", "facebook/dinov2-small")
+    out = m(G.to_gpu(synth.make_pixels(2, 224, 224, seed=0)))
+    G.sync()
+    assert rel_err(out["pred_logits"].cpu().numpy(), g["pred_logits"]) < 1e-2
+    assert rel_err(out["pred_boxes"].cpu().numpy(), g["pred_boxes"]) < 1e-2
+
+
+def test_weights_resync_after_load_state_dict(G):
+    """checkpoint-resume path of train.py:695-739: load_state_dict after a forward must take effect."""
+    bb, dc = cases.cfg1(25)
+    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-small")
+    x = G.to_gpu(synth.make_pixels(1, 224, 224, seed=0))
+    a = m.forward_packed(x).clone()
+    sd2 = synth.detector_state_dict(bb, dc, seed=2)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()}, strict=True)
+    b = m.forward_packed(x).clone()
+    assert not torch.allclose(a, b)
+    want = orc.detector_forward(sd2, bb, dc, x.cpu().numpy())
+    assert rel_err(b[..., :91].cpu().numpy(), want["pred_logits"].numpy()) < TOL
+
+
+def test_module_prefix_and_error_paths(G):
+    from dinov2_od_amd import _native as nat
+    bb, dc = cases.cfg1(25)
+    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-small")
+    with pytest.raises(ValueError, match="channel dimension"):
+        m(torch.zeros(1, 4, 224, 224, device=G.dev()))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 8, 8, device=G.dev()))          # smaller than one patch
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 224, 224))

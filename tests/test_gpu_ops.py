@@ -1,0 +1,192 @@
+"""`-m gpu`: every HIP kernel, called through the C ABI's operator entry points, against the CPU
+oracle / a plain fp32 torch statement of the same op, on seeded inputs.  Tolerances are written
+next to each comparison: fp32 kernels 1e-5-level (summation order only); bf16 kernels are
+compared with the SAME bf16-rounded operands evaluated in fp32 on the CPU."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dinov2_od_amd import _native as nat
+from dinov2_od_amd import synth
+from oracle import dinodet_oracle as orc
+from tests.cases import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (run with -m 'not gpu' on CPU)")
+    from tests import gpu_util
+    nat.lib()
+    return gpu_util
+
+
+def _n(key, shape, std=1.0):
+    return synth.normal(11, key, shape, std)
+
+
+@pytest.mark.parametrize("rows,D", [(7, 128), (1000, 384), (2740, 768), (513, 1536)])
+def test_layernorm(G, rows, D):
+    x, g, b = _n("ln.x", (rows, D), 2.0) + 0.5, 1 + _n("ln.g", (D,), 0.1), _n("ln.b", (D,), 0.1)
+    add = _n("ln.add", (rows, D))
+    L = nat.lib()
+    for use_add in (False, True):
+        want = F.layer_norm(torch.from_numpy(x + (add if use_add else 0)), (D,), torch.from_numpy(g), torch.from_numpy(b), 1e-6)
+        xd, gd, bd, ad = G.to_gpu(x), G.to_gpu(g), G.to_gpu(b), G.to_gpu(add)
+        out = torch.empty(rows, D, device=G.dev())
+        nat.check(L.dod_op_layernorm(nat.ptr(xd), nat.ptr(ad) if use_add else None, nat.ptr(gd), nat.ptr(bd), 1e-6, rows, D,
+                                     nat.ptr(out), nat.DOD_F32, nat.stream_ptr()))
+        assert rel_err(out.cpu().numpy(), want.numpy()) < 2e-6
+        outb = torch.empty(rows, D, device=G.dev(), dtype=torch.bfloat16)
+        nat.check(L.dod_op_layernorm(nat.ptr(xd), nat.ptr(ad) if use_add else None, nat.ptr(gd), nat.ptr(bd), 1e-6, rows, D,
+                                     nat.ptr(outb), nat.DOD_BF16, nat.stream_ptr()))
+        # bf16 output = RNE of the fp32 result (one-ulp slack for results on a rounding boundary)
+        assert rel_err(outb.float().cpu().numpy(), want.to(torch.bfloat16).float().numpy()) < 2 ** -7
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (100, 50, 768), (800, 91, 768), (1370, 768, 588), (333, 200, 132), (2740, 2304, 768)])
+def test_linear_f32_all_epilogues(G, M, N, K):
+    A, W = _n("f.A", (M, K)), _n("f.W", (N, K), 0.05)
+    bias, scale, resid = _n("f.b", (N,)), 1 + _n("f.s", (N,), 0.1), _n("f.r", (M, N))
+    ref = torch.from_numpy(A).double() @ torch.from_numpy(W).double().t()
+    Ad, Wd = G.to_gpu(A), G.to_gpu(W)
+    out = G.op_linear(Ad, Wd)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 3e-6
+    for act, fn in (("relu", torch.relu), ("gelu", lambda t: F.gelu(t)), ("sigmoid", torch.sigmoid)):
+        want = fn(ref + torch.from_numpy(bias).double()) * torch.from_numpy(scale).double() + torch.from_numpy(resid).double()
+        out = G.op_linear(Ad, Wd, G.to_gpu(bias), G.to_gpu(scale), G.to_gpu(resid), act)
+        assert rel_err(out.cpu().numpy(), want.numpy()) < 3e-6, act
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (128, 128, 64), (257, 384, 128), (1370, 768, 640), (2740, 2304, 768), (1111, 200, 3072)])
+def test_linear_bf16_all_epilogues(G, M, N, K):
+    A = torch.from_numpy(_n("b.A", (M, K))).to(torch.bfloat16)
+    W = torch.from_numpy(_n("b.W", (N, K), 0.05)).to(torch.bfloat16)
+    bias, scale, resid = _n("b.b", (N,)), 1 + _n("b.s", (N,), 0.1), _n("b.r", (M, N))
+    ref = A.double() @ W.double().t()      # exact products of the same bf16 operands
+    Ad, Wd = A.to(G.dev()), W.to(G.dev())
+    out = G.op_linear(Ad, Wd)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 3e-6       # fp32 accumulation only
+    want = F.gelu(ref + torch.from_numpy(bias).double())
+    out = G.op_linear(Ad, Wd, G.to_gpu(bias), None, None, "gelu", torch.bfloat16)
+    assert rel_err(out.float().cpu().numpy(), want.numpy()) < 2 ** -7     # bf16 output rounding
+    want = (ref + torch.from_numpy(bias).double()) * torch.from_numpy(scale).double() + torch.from_numpy(resid).double()
+    r = G.to_gpu(resid)
+    out = G.op_linear(Ad, Wd, G.to_gpu(bias), G.to_gpu(scale), r, "none")
+    assert rel_err(out.cpu().numpy(), want.numpy()) < 3e-6
+
+
+def test_linear_rejects_bad_shapes(G):
+    A = torch.zeros(8, 100, device=G.dev(), dtype=torch.bfloat16)
+    W = torch.zeros(8, 100, device=G.dev(), dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        G.op_linear(A, W)            # K % 64 != 0 for the bf16 kernel
+    with pytest.raises(ValueError):
+        G.op_linear(torch.zeros(8, 6, device=G.dev()), torch.zeros(8, 6, device=G.dev()))   # K % 4
+
+
+def _attn_ref(q, k, v, scale):
+    s = (q.double() @ k.double().transpose(-1, -2)) * scale
+    return torch.softmax(s, -1) @ v.double()
+
+
+@pytest.mark.parametrize("B,N,heads", [(1, 17, 2), (2, 64, 1), (2, 257, 6), (1, 1370, 12), (3, 130, 2)])
+def test_attention_bf16(G, B, N, heads):
+    D = heads * 64
+    qkv = torch.from_numpy(_n(f"a.qkv{N}", (B, N, 3 * D), 1.5)).to(torch.bfloat16)
+    L = nat.lib()
+    qd = qkv.to(G.dev()).contiguous()
+    ctx = torch.empty(B, N, D, device=G.dev(), dtype=torch.bfloat16)
+    nat.check(L.dod_op_attention_bf16(nat.ptr(qd), nat.ptr(ctx), B, N, heads, 0.125, nat.stream_ptr()))
+    q, k, v = [t.view(B, N, heads, 64).transpose(1, 2) for t in qkv.float().split(D, dim=-1)]
+    want = _attn_ref(q, k, v, 0.125).transpose(1, 2).reshape(B, N, D)
+    # P is rounded to bf16 before P.V and the context is stored in bf16: 2^-8-level relative error
+    assert rel_err(ctx.float().cpu().numpy(), want.numpy()) < 1e-2
+    assert float(np.abs(ctx.float().cpu().numpy() - want.numpy()).mean() / np.abs(want.numpy()).mean()) < 3e-3
+
+
+def test_attention_bf16_forced_rescale(G):
+    """Online-softmax rescale path: one key per later tile dominates every row (cdna guide rule 26)."""
+    B, N, heads, D = 1, 300, 1, 64
+    x = _n("a.spike", (B, N, 3 * D), 0.5)
+    x[0, 70, D:2 * D] *= 8.0      # key 70 (tile 1) spikes
+    x[0, 200, D:2 * D] *= 16.0    # key 200 (tile 3) spikes more
+    qkv = torch.from_numpy(x).to(torch.bfloat16)
+    qd = qkv.to(G.dev())
+    ctx = torch.empty(B, N, D, device=G.dev(), dtype=torch.bfloat16)
+    nat.check(nat.lib().dod_op_attention_bf16(nat.ptr(qd), nat.ptr(ctx), B, N, heads, 0.125, nat.stream_ptr()))
+    q, k, v = [t.view(B, N, heads, 64).transpose(1, 2) for t in qkv.float().split(D, dim=-1)]
+    want = _attn_ref(q, k, v, 0.125).transpose(1, 2).reshape(B, N, D)
+    assert rel_err(ctx.float().cpu().numpy(), want.numpy()) < 1e-2
+
+
+@pytest.mark.parametrize("B,Lq,Lk,heads,dh", [(2, 7, 7, 4, 32), (2, 100, 100, 8, 96), (1, 300, 300, 8, 96), (2, 5, 1370, 2, 96),
+                                             (1, 257, 257, 6, 64), (2, 33, 70, 3, 128), (1, 9, 17, 5, 48)])
+def test_attention_f32(G, B, Lq, Lk, heads, dh):
+    E = heads * dh
+    q, k, v = _n("g.q", (B, Lq, E)), _n("g.k", (B, Lk, E)), _n("g.v", (B, Lk, E))
+    qd, kd, vd = G.to_gpu(q), G.to_gpu(k), G.to_gpu(v)
+    o = torch.empty(B, Lq, E, device=G.dev())
+    sc = 1.0 / math.sqrt(dh)
+    nat.check(nat.lib().dod_op_attention_f32(nat.ptr(qd), nat.ptr(kd), nat.ptr(vd), nat.ptr(o), E, E, E, E, Lq, Lk, B, heads, dh, sc,
+                                             nat.stream_ptr()))
+    sp = lambda t, L: torch.from_numpy(t).view(B, L, heads, dh).transpose(1, 2)
+    want = _attn_ref(sp(q, Lq), sp(k, Lk), sp(v, Lk), sc).transpose(1, 2).reshape(B, Lq, E)
+    assert rel_err(o.cpu().numpy(), want.numpy()) < 5e-6
+
+
+@pytest.mark.parametrize("N,Hd,dh,P", [(17, 4, 32, 2), (26, 2, 96, 2), (257, 8, 96, 2), (1370, 8, 96, 2), (1370, 4, 64, 4), (256, 2, 128, 1)])
+def test_deform_sample_matches_oracle(G, N, Hd, dh, P):
+    from dinov2_od_amd.config import spatial_factor
+    B, Q, Dd = 2, 9, Hd * dh
+    h, w = spatial_factor(N)
+    ncat = 2 + 3 * Hd * P
+    proj = _n("d.proj", (B * Q, ncat), 1.0)
+    proj[:, 2:2 + Hd * P * 2] *= 0.3                 # offsets: some samples clamp at 0/1, most do not
+    proj[0, 0] = 30.0                                # reference point exactly at the right edge (x1 clamp path)
+    proj[1, 0] = -30.0                               # and at the left edge
+    vals = _n("d.vals", (B, N, Dd))
+    out = torch.empty(B * Q, Dd, device=G.dev())
+    nat.check(nat.lib().dod_op_deform_sample(nat.ptr(G.to_gpu(proj)), ncat, nat.ptr(G.to_gpu(vals)), B, Q, N, Hd, P, dh, h, w,
+                                             nat.ptr(out), nat.stream_ptr()))
+    pr = torch.from_numpy(proj).view(B, Q, ncat)
+    ref = torch.sigmoid(pr[..., :2])
+    off = pr[..., 2:2 + Hd * P * 2].reshape(B, Q, Hd, P, 2)
+    aw = pr[..., 2 + Hd * P * 2:].reshape(B, Q, Hd, P).softmax(-1)
+    want = orc.deformable_sample(torch.from_numpy(vals).view(B, N, Hd, dh), ref, off, aw, h, w).reshape(B * Q, Dd)
+    assert rel_err(out.cpu().numpy(), want.numpy()) < 1e-5
+
+
+def test_deform_sample_rejects_bad_grid(G):
+    with pytest.raises(ValueError, match="Cannot reshape"):
+        z = torch.zeros(64, device=G.dev())
+        nat.check(nat.lib().dod_op_deform_sample(nat.ptr(z), 8, nat.ptr(z), 1, 1, 10, 1, 2, 4, 3, 3, nat.ptr(z), nat.stream_ptr()))
+
+
+@pytest.mark.parametrize("G_,gh,gw,D", [(5, 4, 4, 128), (37, 16, 16, 768), (37, 37, 20, 64), (5, 9, 7, 64)])
+def test_pos_resize_matches_torch_bicubic(G, G_, gh, gw, D):
+    pos = _n("p.pos", (G_ * G_ + 1, D), 0.02)
+    out = torch.empty(gh * gw + 1, D, device=G.dev())
+    nat.check(nat.lib().dod_op_pos_resize(nat.ptr(G.to_gpu(pos)), G_, gh, gw, D, nat.ptr(out), nat.stream_ptr()))
+    p = torch.from_numpy(pos[1:]).reshape(1, G_, G_, D).permute(0, 3, 1, 2)
+    want = F.interpolate(p, size=(gh, gw), mode="bicubic", align_corners=False).permute(0, 2, 3, 1).reshape(-1, D)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[0], pos[0])
+    assert rel_err(got[1:], want.numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 56, 70), (1, 224, 224), (1, 518, 518), (1, 30, 45)])
+def test_im2col_is_exact(G, B, H, W):
+    img = synth.make_pixels(B, H, W, seed=2)
+    p, K, Kp = 14, 588, 640
+    gh, gw = H // p, W // p
+    out = torch.empty(B * gh * gw, Kp, device=G.dev())
+    nat.check(nat.lib().dod_op_im2col(nat.ptr(G.to_gpu(img)), B, H, W, p, Kp, nat.ptr(out), nat.DOD_F32, nat.stream_ptr()))
+    x = torch.from_numpy(img)[:, :, :gh * p, :gw * p].reshape(B, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, K)
+    got = out.cpu()
+    assert torch.equal(got[:, :K], x) and float(got[:, K:].abs().max()) == 0.0

@@ -1,0 +1,107 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/dinodet.h declares, argument validation returns the documented status codes, and the
+Python mirrors expose the reference's state-dict keys.  No GPU compute."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from dinov2_od_amd import _native as nat
+from dinov2_od_amd import synth
+from dinov2_od_amd.engine import make_config
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(nat.LIB_PATH):
+        from dinov2_od_amd._build import build
+        build(verbose=False)
+    return nat.lib()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "dinodet.h")).read()
+    declared = set(re.findall(r"\b(dod_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(nat.SYMBOLS), (declared ^ set(nat.SYMBOLS))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.dod_version()
+
+
+def test_config_struct_layout_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "dinodet.h")).read()
+    body = re.search(r"typedef struct dod_config \{(.*?)\} dod_config;", hdr, re.S).group(1)
+    fields = re.findall(r"^\s*(int32_t|float)\s+(\w+);", body, re.M)
+    assert [f for _, f in fields] == [f for f, _ in nat.DodConfig._fields_]
+    for (ct, _), (_, pt) in zip(fields, nat.DodConfig._fields_):
+        assert (ct == "float") == (pt is C.c_float)
+    assert C.sizeof(nat.DodConfig) == 4 * len(fields)
+
+
+def test_create_validates_arguments(lib):
+    bb, dc = cases.cfg1(25)
+    h = C.c_void_p()
+    cfg = make_config(bb, dc, "bf16")
+    assert lib.dod_create(C.byref(cfg), C.byref(h)) == 0
+    # not finalized -> state error, message available
+    assert lib.dod_workspace_bytes(h, 0, 224, 224) == 0
+    rc = lib.dod_forward(h, None, 1, 224, 224, None, None, 0, None)
+    assert rc == 3 and b"finalize" in lib.dod_last_error(h)
+    rc = lib.dod_finalize_weights(h, None)
+    assert rc == 2 and b"weights" in lib.dod_last_error(h)      # nothing registered
+    lib.dod_destroy(h)
+    bad = make_config(bb, dc, "bf16")
+    bad.heads = 5                                                # 384 % 5 != 0
+    h2 = C.c_void_p()
+    assert lib.dod_create(C.byref(bad), C.byref(h2)) == 1
+    assert b"backbone dims" in lib.dod_last_error(None)
+    bad = make_config(bb, dc, "bf16")
+    bad.target_dim = 128                                         # != decoder hidden 256
+    assert lib.dod_create(C.byref(bad), C.byref(h2)) == 1
+    with pytest.raises(ValueError):
+        make_config(bb, dc, "fp8")
+
+
+@pytest.mark.parametrize("deform", [True, False])
+def test_state_dict_keys_match_reference_layout(deform):
+    """Keys/shapes equal the synthetic state dict, which tests/golden/make_goldens.py loads
+    into the REFERENCE modules with strict=True."""
+    from dinov2_od_amd.models import DINOv2ObjectDetector
+    m = DINOv2ObjectDetector(dino_model_name="facebook/dinov2-small", hidden_dim=256, nheads=4, num_queries=25,
+                             num_decoder_layers=2, dim_feedforward=512, lora_r=1, use_deformable=deform,
+                             pretrained=False)
+    bb, dc = cases.cfg1(25)
+    dc.use_deformable = deform
+    ref = synth.detector_state_dict(bb, dc)
+    sd = m.state_dict()
+    assert set(sd) == set(ref)
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == v.shape, k
+    # frozen backbone, trainable LoRA / projection / decoder (dinov2_backbone.py:40-51)
+    trainable = {k for k, p in m.named_parameters() if p.requires_grad}
+    assert all(("lora_" in k) or k.startswith("decoder.") or k.startswith("backbone.projection") for k in trainable)
+    assert any("lora_A" in k for k in trainable)
+    if deform:   # tied decoder layers alias one storage (deformable_attention.py:284)
+        a = m.state_dict(keep_vars=True)
+        assert a["decoder.decoder.layers.0.linear1.weight"].data_ptr() == a["decoder.decoder.layers.1.linear1.weight"].data_ptr()
+
+
+def test_forward_without_gpu_fails_loudly():
+    from dinov2_od_amd.models import DINOv2ObjectDetector
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = DINOv2ObjectDetector(dino_model_name="facebook/dinov2-small", hidden_dim=256, nheads=4, num_queries=5,
+                             num_decoder_layers=1, dim_feedforward=64, lora_r=1, pretrained=False).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 224, 224))
+    with pytest.raises(ValueError, match="channel dimension"):
+        m(torch.zeros(1, 4, 224, 224))
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 3, 224, 224))
