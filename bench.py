@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of DINOv2ObjectDetector.forward on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W            (single GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W   (one rank per GPU, RCCL)
+
+A "step" is one forward of the hot path over one batch of synthetic images already resident in HBM:
+pixel_values [B,3,518,518] fp32 -> packed detections [B,100,95] fp32 (multi-GPU: after the single
+RCCL all-gather of the packed detections).  Workload at every N: BASELINE.json configs[2]'s per-GPU
+share -- ViT-B/14 518x518, 100 queries, batch 8 per GPU (64 over 8 GPUs) -- i.e. weak scaling.
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline     : the dominant kernel (bf16 MFMA GEMM) -- algorithmic FLOPs / its summed launch time,
+                 measured with HIP events on the launch stream by the library's profile mode over
+                 extra forwards of the same step, right after the timed region;
+  cpu_baseline : the CPU oracle (kind "port": oracle/dinodet_oracle.py, the parity-checked CPU
+                 restatement of the reference) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+WORKLOADS = {
+    # name: (model name, R, queries, per-GPU batch, description)
+    "vitb518": ("facebook/dinov2-base", 518, 100, 8, "ViT-B/14 518x518 bf16, 100 queries, batch 8 per GPU (BASELINE configs[2]: 64 over 8 GPUs)"),
+    "vitb224": ("facebook/dinov2-base", 224, 100, 32, "ViT-B/14 224x224 bf16, 100 queries, batch 32 per GPU (BASELINE configs[1])"),
+    "vitl518": ("facebook/dinov2-large", 518, 300, 16, "ViT-L/14 518x518 bf16, 300 queries, batch 16 per GPU (BASELINE configs[3])"),
+    "vits224": ("facebook/dinov2-small", 224, 100, 2, "--lightweight ViT-S/14 224x224, batch 2 (BASELINE configs[0])"),
+}
+PEAK_BF16 = 2.5e15      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32 = 157.3e12
+
+
+def build(name, queries, precision, device):
+    from dinov2_od_amd.models import DINOv2ObjectDetector
+    from dinov2_od_amd.config import BackboneConfig, DecoderConfig
+    from dinov2_od_amd import synth
+    kw = dict(num_queries=queries)
+    if "small" in name:   # train.py:607-640 lightweight preset
+        kw.update(hidden_dim=256, num_decoder_layers=2, dim_feedforward=512, lora_r=1, nheads=4)
+    m = DINOv2ObjectDetector(dino_model_name=name, pretrained=False, precision=precision, **kw)
+    bb, dc = m._bb_cfg, m._dc_cfg
+    sd = synth.detector_state_dict(bb, dc, seed=1)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    del sd
+    return m.to(device).eval(), bb, dc
+
+
+def cpu_baseline(bb, dc, R, seconds_budget=20.0):
+    """oracle on the host cores: bounded sample (>= 1 batch of 2 images, up to the time budget)."""
+    from oracle import dinodet_oracle as orc
+    from dinov2_od_amd import synth
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = {k: torch.from_numpy(v) for k, v in synth.detector_state_dict(bb, dc, seed=1).items()}
+    x = torch.from_numpy(synth.make_pixels(2, R, R, seed=0))
+    orc.detector_forward(sd, bb, dc, x[:1])          # warm-up (thread pools, first-touch)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.detector_forward(sd, bb, dc, x)
+        n += 2
+        if time.perf_counter() - t0 > seconds_budget or n >= 32:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} images (batches of 2) of the same workload, fp32, torch {torch.__version__} CPU, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="vitb518", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
+    a = ap.parse_args()
+
+    from dinov2_od_amd import dist as ddist
+    from dinov2_od_amd.config import flops_per_image
+    rank, world, local = ddist.init_from_env("nccl" if torch.cuda.is_available() else None)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    name, R, Q, B_local, desc = WORKLOADS[a.workload]
+    if a.batch:
+        B_local = a.batch
+        desc += f" [per-GPU batch overridden to {B_local}]"
+    from dinov2_od_amd import synth
+    model, bb, dc = build(name, Q, a.precision, device)
+    lo, hi = ddist.shard_bounds(B_local * world, rank, world)
+    x = torch.empty(B_local, 3, R, R, device=device)
+    for i, g in enumerate(range(lo, hi)):          # image g of the global batch, resident in HBM
+        x[i] = torch.from_numpy(synth.uniform01(0, f"pixel_values.{R}x{R}.{g % 8}", (3, R, R))).to(device)
+    gathered = torch.empty(B_local * world, Q, dc.num_classes + 4, device=device) if world > 1 else None
+
+    def step():
+        det = model.forward_packed(x)
+        return ddist.gather_detections_equal(det, gathered) if world > 1 else det
+
+    with torch.no_grad():
+        out = step()                                # packs weights, sizes workspace, sets func attributes
+        torch.cuda.synchronize()
+        use_graph = not a.no_graph and world == 1
+        graph = None
+        if use_graph:
+            try:
+                static_out = None
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    step()
+                torch.cuda.current_stream().wait_stream(s)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = step()
+                run = graph.replay
+            except Exception as e:                  # capture unsupported -> eager, say so
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+                graph, use_graph = None, False
+                run = step
+        else:
+            run = step
+        for _ in range(a.warmup):
+            run()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            run()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+
+        # ---- roofline leg: same step, library event timing per kernel class (eager, outside the timed region)
+        eng = model._get_engine()
+        nprof = max(3, min(10, a.steps))
+        eng.profile(True)
+        for _ in range(nprof):
+            model.forward_packed(x)
+        torch.cuda.synchronize()
+        prof = eng.profile_read()
+        eng.profile(False)
+
+    global_batch = B_local * world
+    ips = global_batch * a.steps / dt
+    fpi = flops_per_image(bb, dc, R, R)
+    dom = "gemm_bf16" if a.precision == "bf16" else "gemm_f32"
+    peak = PEAK_BF16 if a.precision == "bf16" else PEAK_F32
+    d = prof[dom]
+    ach = d["flops"] / (d["ms"] * 1e-3) if d["ms"] > 0 else 0.0
+    roof = {"bound": "mfma", "kernel": dom + "_kernel", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+            "frac": ach / peak, "traffic": None,
+            "launches_per_step": d["launches"] // nprof, "avg_launch_us": 1e3 * d["ms"] / max(1, d["launches"]),
+            "flops_per_launch_avg": d["flops"] / max(1, d["launches"]),
+            "other_kernels": {k: {"ms_per_step": v["ms"] / nprof, "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None}
+                              for k, v in prof.items() if v["launches"]}}
+    res = {"metric": "images/sec forward, DINOv2 ViT-B/14 518x518 + 100-query head" if a.workload == "vitb518" else f"images/sec forward, {a.workload}",
+           "value": ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": a.precision, "data": "synthetic",
+           "config": {"workload": desc, "global_batch": global_batch, "per_gpu_batch": B_local, "image": R, "queries": Q,
+                      "parallelism": f"dp{world}", "hipgraph": bool(use_graph),
+                      "gflop_per_image": fpi / 1e9},
+           "mfma_roofline_frac_end_to_end": ips * fpi / (peak * world),
+           "roofline": roof}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(bb, dc, R)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

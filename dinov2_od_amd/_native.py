@@ -44,6 +44,8 @@ SYMBOLS = {
     "dod_decoder_forward": (_I, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
     "dod_decoder_workspace_bytes": (_SZ, [_P, _I, _I]),
     "dod_set_tap": (_I, [_P, _I, _P]),
+    "dod_profile": (_I, [_P, _I]),
+    "dod_profile_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dod_op_linear": (_I, [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "dod_op_layernorm": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _I, _P]),
     "dod_op_attention_bf16": (_I, [_P, _P, _I, _I, _I, _F, _P]),

@@ -55,6 +55,11 @@ struct dod_handle {
   // position-table cache
   int pos_H = -1, pos_W = -1; float* pos_hw = nullptr; size_t pos_hw_elems = 0;
   std::map<int, float*> taps;
+  // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
+  bool prof_on = false;
+  struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> evpool;
 };
 
 namespace {
@@ -69,6 +74,29 @@ int fail(const dod_handle* h, int code, const char* fmt, ...) {
 }
 #define HIPCHK(h, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(h, DOD_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
 #define KCHK(h, x) do { int r_ = (x); if (r_) return fail(h, r_ == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "kernel launch failed (%d): %s", r_, #x); } while (0)
+
+enum { PC_GEMM_BF16 = 0, PC_ATTN_BF16 = 1, PC_GEMM_F32 = 2, PC_ATTN_F32 = 3, PC_LAYERNORM = 4, PC_OTHER = 5, PC_COUNT = 6 };
+struct ProfScope {
+  dod_handle* h; hipStream_t s; int cls; double flops; hipEvent_t a = nullptr;
+  ProfScope(dod_handle* h_, hipStream_t s_, int cls_, double flops_) : h(h_), s(s_), cls(cls_), flops(flops_) {
+    if (!h->prof_on) return;
+    a = take();
+    if (a) (void)hipEventRecord(a, s);
+  }
+  hipEvent_t take() {
+    hipEvent_t e = nullptr;
+    if (!h->evpool.empty()) { e = h->evpool.back(); h->evpool.pop_back(); return e; }
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+  ~ProfScope() {
+    if (!h->prof_on || !a) return;
+    hipEvent_t b = take();
+    if (!b) { h->evpool.push_back(a); return; }
+    (void)hipEventRecord(b, s);
+    h->prof.push_back({a, b, cls, flops});
+  }
+};
 
 inline bool is_bf16(const dod_handle* h) { return h->cfg.precision == DOD_PREC_BF16; }
 inline size_t esz(const dod_handle* h) { return is_bf16(h) ? 2 : 4; }
@@ -349,6 +377,7 @@ int tap(dod_handle* h, int stage, const void* src, bool src_bf16, size_t n, hipS
 
 // generic linear on the precision's operand dtype
 int linear(dod_handle* h, bool bf, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+  ProfScope ps(h, s, bf ? PC_GEMM_BF16 : PC_GEMM_F32, 2.0 * M * N * (e.rows_per_img > 0 ? 3.0 * h->cfg.patch * h->cfg.patch : (double)K));
   int r = bf ? launch_gemm_bf16((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, e, s)
              : launch_gemm_f32((const float*)A, lda, (const float*)W, ldw, M, N, K, e, s);
   if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "linear launch rejected (M=%d N=%d K=%d bf16=%d rc=%d)", M, N, K, (int)bf, r);
@@ -382,17 +411,18 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   float* yf = bf ? nullptr : (float*)ws.y; bf16_t* yb = bf ? (bf16_t*)ws.y : nullptr;
   for (int i = 0; i < g.layers; ++i) {
     const BLayer& L = h->L[i];
-    KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, yf, yb, s));                       // K3
+    { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, yf, yb, s)); }   // K3
     rc = linear(h, bf, ws.y, D, L.Wqkv, D, M, 3 * D, D, epi(L.bqkv, bf ? nullptr : (float*)ws.qkv, bf ? ws.qkv : nullptr, 3 * D), s); if (rc) return rc;  // K4
-    if (bf) { KCHK(h, launch_attn_bf16((const bf16_t*)ws.qkv, (bf16_t*)ws.ctx, B, N, g.heads, scale, s)); }    // K5
+    if (bf) { ProfScope ps(h, s, PC_ATTN_BF16, 4.0 * B * (double)N * N * D); KCHK(h, launch_attn_bf16((const bf16_t*)ws.qkv, (bf16_t*)ws.ctx, B, N, g.heads, scale, s)); }    // K5
     else {
+      ProfScope ps(h, s, PC_ATTN_F32, 4.0 * B * (double)N * N * D);
       AttnF32 a; const float* q = (const float*)ws.qkv;
       a.q = q; a.k = q + D; a.v = q + 2 * D; a.o = (float*)ws.ctx; a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
       a.Lq = a.Lk = N; a.B = B; a.heads = g.heads; a.dh = D / g.heads; a.scale = scale;
       KCHK(h, launch_attn_f32(a, s));
     }
     rc = linear(h, bf, ws.ctx, D, L.Wo, D, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;   // K6
-    KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, yf, yb, s));
+    { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, yf, yb, s)); }
     if (g.swiglu) {                                                                                            // K7g
       rc = linear(h, bf, ws.y, D, L.W1, D, M, 2 * F, D, epi(L.b1, bf ? nullptr : (float*)ws.hbuf, bf ? ws.hbuf : nullptr, 2 * F), s); if (rc) return rc;
       KCHK(h, launch_swiglu(bf ? nullptr : (const float*)ws.hbuf, bf ? (const bf16_t*)ws.hbuf : nullptr, M, F, bf ? nullptr : (float*)ws.gated, bf ? (bf16_t*)ws.gated : nullptr, s));
@@ -528,7 +558,8 @@ int dod_create(const dod_config* cfg, dod_handle** out) {
   if (!cfg || !out) return fail(nullptr, DOD_ERR_INVALID, "null argument");
   const dod_config& c = *cfg;
   if (c.hidden <= 0 || c.layers <= 0 || c.heads <= 0 || c.hidden % c.heads) return fail(nullptr, DOD_ERR_INVALID, "bad backbone dims hidden=%d heads=%d layers=%d", c.hidden, c.heads, c.layers);
-  if (c.hidden % 64 || c.ffn_hidden % 64) return fail(nullptr, DOD_ERR_INVALID, "hidden (%d) and ffn_hidden (%d) must be multiples of 64", c.hidden, c.ffn_hidden);
+  if (c.hidden % 64) return fail(nullptr, DOD_ERR_INVALID, "hidden (%d) must be a multiple of 64", c.hidden);
+  if (c.ffn_hidden <= 0 || c.ffn_hidden % (c.precision == DOD_PREC_BF16 ? 64 : 4)) return fail(nullptr, DOD_ERR_INVALID, "ffn_hidden (%d) must be a multiple of %d in this precision", c.ffn_hidden, c.precision == DOD_PREC_BF16 ? 64 : 4);
   if (c.patch <= 0 || c.pos_grid <= 0) return fail(nullptr, DOD_ERR_INVALID, "bad patch/pos_grid");
   if (c.num_queries <= 0 || c.dec_hidden <= 0 || c.dec_heads <= 0 || c.dec_layers <= 0 || c.num_classes <= 0 || c.dim_feedforward <= 0) return fail(nullptr, DOD_ERR_INVALID, "bad decoder dims");
   if (c.dec_hidden % 64 || c.dim_feedforward % 4) return fail(nullptr, DOD_ERR_INVALID, "decoder hidden (%d) must be a multiple of 64, dim_feedforward (%d) of 4", c.dec_hidden, c.dim_feedforward);
@@ -546,6 +577,8 @@ int dod_create(const dod_config* cfg, dod_handle** out) {
 
 void dod_destroy(dod_handle* h) {
   if (!h) return;
+  for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : h->evpool) (void)hipEventDestroy(e);
   for (void* p : h->owned) (void)hipFree(p);
   delete h;
 }
@@ -639,6 +672,28 @@ int dod_decoder_forward(dod_handle* h, const float* memory, int B, int N, float*
     mem_op = dw.mem_op;
   }
   return decoder_impl(h, mem_op, B, N, dw, det, s);
+}
+
+int dod_profile(dod_handle* h, int enable) {
+  if (!h) return fail(nullptr, DOD_ERR_INVALID, "null handle");
+  for (auto& r : h->prof) { h->evpool.push_back(r.a); h->evpool.push_back(r.b); }
+  h->prof.clear();
+  h->prof_on = enable != 0;
+  return DOD_OK;
+}
+
+int dod_profile_read(dod_handle* h, int cls, double* ms, double* flops, int* launches) {
+  if (!h || cls < 0 || cls >= PC_COUNT) return fail(h, DOD_ERR_INVALID, "bad profile class");
+  double t = 0, f = 0; int n = 0;
+  for (auto& r : h->prof) {
+    if (r.cls != cls) continue;
+    HIPCHK(h, hipEventSynchronize(r.b));
+    float e = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&e, r.a, r.b));
+    t += e; f += r.flops; ++n;
+  }
+  if (ms) *ms = t; if (flops) *flops = f; if (launches) *launches = n;
+  return DOD_OK;
 }
 
 // ---- stateless ops

@@ -139,6 +139,20 @@ class Engine:
                                                 nat.stream_ptr()), self._h)
         return det
 
+    # ------------------------------------------------------------------ per-kernel timing (bench roofline leg)
+    PROFILE_CLASSES = {"gemm_bf16": 0, "attn_bf16": 1, "gemm_f32": 2, "attn_f32": 3, "layernorm": 4}
+
+    def profile(self, enable):
+        nat.check(self._lib.dod_profile(self._h, int(bool(enable))), self._h)
+
+    def profile_read(self):
+        out = {}
+        for name, cls in self.PROFILE_CLASSES.items():
+            ms, fl, n = C.c_double(), C.c_double(), C.c_int()
+            nat.check(self._lib.dod_profile_read(self._h, cls, C.byref(ms), C.byref(fl), C.byref(n)), self._h)
+            out[name] = {"ms": ms.value, "flops": fl.value, "launches": n.value}
+        return out
+
     # ------------------------------------------------------------------ debug taps (parity tests)
     def set_tap(self, stage, shape, device):
         buf = torch.zeros(*shape, dtype=torch.float32, device=device)

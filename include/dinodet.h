@@ -116,6 +116,14 @@ size_t dod_decoder_workspace_bytes(const dod_handle* h, int B, int N);
  * output [B,Q,Dd].  dst = NULL clears the tap. */
 int dod_set_tap(dod_handle* h, int stage, float* dst);
 
+/* Per-kernel-class timing with HIP events recorded on the caller's stream around each launch of the
+ * forward (used by bench.py's roofline leg; adds an event pair per launch, so it is off in the timed
+ * region).  dod_profile(h, 1) clears and enables, forwards accumulate, dod_profile_read() waits for the
+ * events and returns summed milliseconds, algorithmic FLOPs (2*M*N*K resp. 4*B*N*N*D) and launches.
+ * cls: 0 bf16 MFMA GEMM, 1 bf16 flash attention, 2 fp32 MFMA GEMM, 3 fp32 attention, 4 backbone LayerNorm. */
+int dod_profile(dod_handle* h, int enable);
+int dod_profile_read(dod_handle* h, int cls, double* ms, double* flops, int* launches);
+
 /* ---- stateless operator entry points (the same kernels the forward uses; for parity tests) ------ */
 enum dod_dtype { DOD_F32 = 0, DOD_BF16 = 1 };
 enum dod_act { DOD_ACT_NONE = 0, DOD_ACT_RELU = 1, DOD_ACT_GELU = 2, DOD_ACT_SIGMOID = 3 };

@@ -152,7 +152,8 @@ def test_deform_sample_matches_oracle(G, N, Hd, dh, P):
     proj[1, 0] = -30.0                               # and at the left edge
     vals = _n("d.vals", (B, N, Dd))
     out = torch.empty(B * Q, Dd, device=G.dev())
-    nat.check(nat.lib().dod_op_deform_sample(nat.ptr(G.to_gpu(proj)), ncat, nat.ptr(G.to_gpu(vals)), B, Q, N, Hd, P, dh, h, w,
+    pd, vd = G.to_gpu(proj), G.to_gpu(vals)      # keep the device tensors alive across the launch
+    nat.check(nat.lib().dod_op_deform_sample(nat.ptr(pd), ncat, nat.ptr(vd), B, Q, N, Hd, P, dh, h, w,
                                              nat.ptr(out), nat.stream_ptr()))
     pr = torch.from_numpy(proj).view(B, Q, ncat)
     ref = torch.sigmoid(pr[..., :2])
@@ -172,7 +173,8 @@ def test_deform_sample_rejects_bad_grid(G):
 def test_pos_resize_matches_torch_bicubic(G, G_, gh, gw, D):
     pos = _n("p.pos", (G_ * G_ + 1, D), 0.02)
     out = torch.empty(gh * gw + 1, D, device=G.dev())
-    nat.check(nat.lib().dod_op_pos_resize(nat.ptr(G.to_gpu(pos)), G_, gh, gw, D, nat.ptr(out), nat.stream_ptr()))
+    pd = G.to_gpu(pos)
+    nat.check(nat.lib().dod_op_pos_resize(nat.ptr(pd), G_, gh, gw, D, nat.ptr(out), nat.stream_ptr()))
     p = torch.from_numpy(pos[1:]).reshape(1, G_, G_, D).permute(0, 3, 1, 2)
     want = F.interpolate(p, size=(gh, gw), mode="bicubic", align_corners=False).permute(0, 2, 3, 1).reshape(-1, D)
     got = out.cpu().numpy()
@@ -186,7 +188,8 @@ def test_im2col_is_exact(G, B, H, W):
     p, K, Kp = 14, 588, 640
     gh, gw = H // p, W // p
     out = torch.empty(B * gh * gw, Kp, device=G.dev())
-    nat.check(nat.lib().dod_op_im2col(nat.ptr(G.to_gpu(img)), B, H, W, p, Kp, nat.ptr(out), nat.DOD_F32, nat.stream_ptr()))
+    imd = G.to_gpu(img)
+    nat.check(nat.lib().dod_op_im2col(nat.ptr(imd), B, H, W, p, Kp, nat.ptr(out), nat.DOD_F32, nat.stream_ptr()))
     x = torch.from_numpy(img)[:, :, :gh * p, :gw * p].reshape(B, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, K)
     got = out.cpu()
     assert torch.equal(got[:, :K], x) and float(got[:, K:].abs().max()) == 0.0
