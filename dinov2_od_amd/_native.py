@@ -54,6 +54,7 @@ SYMBOLS = {
     "dod_op_pos_resize": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "dod_op_im2col": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "dod_version": (C.c_char_p, []),
+    "dod_device_count": (_I, []),
 }
 
 _lib = None
@@ -63,6 +64,11 @@ def lib():
     """Load the library (once).  Raises if it has not been built."""
     global _lib
     if _lib is None:
+        # libdinodet.so must share ONE HIP runtime with PyTorch (device pointers and streams cross the
+        # ABI).  The PyTorch wheel bundles its own libamdhip64.so and publishes it in the global symbol
+        # scope; importing torch first makes libdinodet's hip* references bind to that copy.  Loaded the
+        # other way round, the process would hold two HIP runtimes.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
@@ -72,6 +78,12 @@ def lib():
             fn = getattr(L, name)   # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        try:
+            if torch.cuda.is_available() and L.dod_device_count() <= 0:
+                raise RuntimeError("libdinodet.so is bound to a different HIP runtime than PyTorch "
+                                   "(it sees no device): import torch before loading it")
+        except AttributeError:
+            pass
         _lib = L
     return _lib
 

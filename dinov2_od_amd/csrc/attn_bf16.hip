@@ -44,29 +44,28 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(qp + 16 * t);
   }
 
-  // staging assignment: 2 chunks of K and 2 of V per thread per tile
-  int srow[2], sc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { const int id = tid + 256 * i; srow[i] = id >> 3; sc[i] = id & 7; }
-  uint4 rk[2], rv[2];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int key = kt * AT_KV + srow[i]; key = key < N ? key : N - 1;
-      const bf16_t* p = base + (size_t)key * ld + D + h * 64 + sc[i] * 8;
-      rk[i] = *reinterpret_cast<const uint4*>(p);
-      rv[i] = *reinterpret_cast<const uint4*>(p + D);
-    }
-  };
-  auto lwrite = [&](int st) {
-    char* sK = smem + st * (2 * AT_KV * 128);
-    char* sV = sK + AT_KV * 128;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<uint4*>(sK + srow[i] * 128 + kswz(srow[i], sc[i]) * 16) = rk[i];
-      *reinterpret_cast<uint4*>(sV + srow[i] * 128 + vswz(srow[i], sc[i]) * 16) = rv[i];
-    }
-  };
+  // staging assignment: 2 chunks of K and 2 of V per thread per tile (rows srow and srow + 32)
+  const int srow = tid >> 3, sc = tid & 7;
+  const bf16_t* kvbase = base + D + h * 64 + sc * 8;
+  const int kls0 = srow * 128 + kswz(srow, sc) * 16;          // (row + 32) has the same swizzle term
+  const int vls0 = srow * 128 + vswz(srow, sc) * 16;
+  uint4 rk0, rk1, rv0, rv1;
+#define AT_GLOAD(kt_)                                                              \
+  {                                                                                \
+    int key0 = (kt_) * AT_KV + srow, key1 = key0 + 32;                             \
+    key0 = key0 < N ? key0 : N - 1; key1 = key1 < N ? key1 : N - 1;                \
+    const bf16_t* p0 = kvbase + (size_t)key0 * ld;                                 \
+    const bf16_t* p1 = kvbase + (size_t)key1 * ld;                                 \
+    rk0 = *reinterpret_cast<const uint4*>(p0); rv0 = *reinterpret_cast<const uint4*>(p0 + D); \
+    rk1 = *reinterpret_cast<const uint4*>(p1); rv1 = *reinterpret_cast<const uint4*>(p1 + D); \
+  }
+#define AT_LWRITE(st_)                                                             \
+  {                                                                                \
+    char* sK_ = smem + (st_) * (2 * AT_KV * 128);                                  \
+    char* sV_ = sK_ + AT_KV * 128;                                                 \
+    *reinterpret_cast<uint4*>(sK_ + kls0) = rk0; *reinterpret_cast<uint4*>(sK_ + kls0 + 4096) = rk1; \
+    *reinterpret_cast<uint4*>(sV_ + vls0) = rv0; *reinterpret_cast<uint4*>(sV_ + vls0 + 4096) = rv1; \
+  }
 
   f32x16 o[2];
 #pragma unroll
@@ -77,11 +76,11 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
   const int g16 = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
 
   const int nkt = (N + AT_KV - 1) / AT_KV;
-  gload(0);
-  lwrite(0);
+  AT_GLOAD(0)
+  AT_LWRITE(0)
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) gload(kt + 1);
+    if (kt + 1 < nkt) AT_GLOAD(kt + 1)
     const char* sK = smem + (kt & 1) * (2 * AT_KV * 128);
     const char* sV = sK + AT_KV * 128;
 
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s4], o[db], 0, 0, 0);
       }
     }
-    if (kt + 1 < nkt) lwrite((kt + 1) & 1);
+    if (kt + 1 < nkt) AT_LWRITE((kt + 1) & 1)
     __syncthreads();
   }
 

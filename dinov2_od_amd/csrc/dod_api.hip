@@ -117,7 +117,9 @@ struct Packer {
   dod_handle* h; hipStream_t s; std::vector<void*> tmp; int rc = 0;
   template <typename T> T* alloc(size_t n, bool temp = false) {
     void* p = nullptr;
-    if (hipMalloc(&p, n * sizeof(T) ? n * sizeof(T) : 4) != hipSuccess) { rc = fail(h, DOD_ERR_HIP, "hipMalloc of %zu bytes failed", n * sizeof(T)); return nullptr; }
+    if (rc) return nullptr;   // keep the FIRST error
+    hipError_t me = hipMalloc(&p, n * sizeof(T) ? n * sizeof(T) : 4);
+    if (me != hipSuccess) { rc = fail(h, DOD_ERR_HIP, "hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(me)); return nullptr; }
     (temp ? tmp : h->owned).push_back(p);
     return (T*)p;
   }
@@ -135,7 +137,8 @@ struct Packer {
   float* copy(const std::string& k, std::initializer_list<int64_t> shape) {
     const WRef* r = need(k, shape); if (!r) return nullptr;
     float* d = alloc<float>(r->numel()); if (!d) return nullptr;
-    if (hipMemcpyAsync(d, r->ptr, r->numel() * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail(h, DOD_ERR_HIP, "copy of '%s' failed", k.c_str());
+    hipError_t ce = hipMemcpyAsync(d, r->ptr, r->numel() * 4, hipMemcpyDeviceToDevice, s);
+    if (ce != hipSuccess && !rc) rc = fail(h, DOD_ERR_HIP, "copy of '%s' failed: %s", k.c_str(), hipGetErrorString(ce));
     return d;
   }
   // effective fp32 weight of a (possibly LoRA-wrapped) linear: returns a device pointer valid until finalize ends
@@ -149,7 +152,7 @@ struct Packer {
       const int r = (int)A->shape[0];
       if (A->shape != std::vector<int64_t>{r, in_f} || Bm->shape != std::vector<int64_t>{out_f, r}) { rc = fail(h, DOD_ERR_INVALID, "bad LoRA shapes for '%s'", prefix.c_str()); return nullptr; }
       float* m = alloc<float>((size_t)out_f * in_f, true); if (!m) return nullptr;
-      if (launch_lora_merge(W->ptr, A->ptr, Bm->ptr, h->cfg.lora_alpha, out_f, in_f, r, m, s)) rc = fail(h, DOD_ERR_HIP, "lora merge launch failed");
+      if (launch_lora_merge(W->ptr, A->ptr, Bm->ptr, h->cfg.lora_alpha, out_f, in_f, r, m, s) && !rc) rc = fail(h, DOD_ERR_HIP, "lora merge launch failed: %s", hipGetErrorString(hipGetLastError()));
       return m;
     }
     const WRef* W = need(prefix + ".weight", {out_f, in_f});
@@ -164,10 +167,10 @@ struct Packer {
     if (!src) return nullptr;
     const bool bf = is_bf16(h) && !force_f32;
     float* f = alloc<float>((size_t)rows * cols_pad, bf); if (!f) return nullptr;
-    if (launch_copy2d(src, cols, f, cols_pad, rows, cols, cols_pad, s)) { rc = fail(h, DOD_ERR_HIP, "copy2d failed"); return nullptr; }
+    if (launch_copy2d(src, cols, f, cols_pad, rows, cols, cols_pad, s)) { if (!rc) rc = fail(h, DOD_ERR_HIP, "copy2d launch failed"); return nullptr; }
     if (!bf) return f;
     bf16_t* b = alloc<bf16_t>((size_t)rows * cols_pad); if (!b) return nullptr;
-    if (launch_cast_bf16(f, b, (size_t)rows * cols_pad, s)) { rc = fail(h, DOD_ERR_HIP, "cast failed"); return nullptr; }
+    if (launch_cast_bf16(f, b, (size_t)rows * cols_pad, s)) { if (!rc) rc = fail(h, DOD_ERR_HIP, "cast launch failed"); return nullptr; }
     return b;
   }
 };
@@ -551,6 +554,11 @@ int launch_widen_bf16(const bf16_t* in, float* out, size_t n, hipStream_t s) {
 extern "C" {
 
 const char* dod_version(void) { return "dinodet 0.1 (gfx950)"; }
+
+int dod_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : -1;
+}
 
 const char* dod_last_error(const dod_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 

@@ -37,6 +37,21 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 // exact-erf GELU (HF ACT2FN["gelu"], modeling_dinov2.py:288-296)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16
+// rounding of the result) with one v_rcp and one v_exp instead of libm erff's ~40-instruction body,
+// which made the fc1 epilogue cost ~25 % of that GEMM.  The fp32 (strict) kernels keep erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+  const float erf_abs = fmaf(-p * t, e, 1.0f);
+  const float erf_v = x < 0.f ? -erf_abs : erf_abs;
+  return 0.5f * x * (1.0f + erf_v);
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ----------------------------------------------------------------------------- epilogue description

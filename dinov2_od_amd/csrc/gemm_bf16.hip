@@ -9,11 +9,15 @@
 // TRANSPOSED (D = W_tile * A_tile^T) so that a lane owns one output row m and its registers
 // run along n: 4 consecutive n per register quad -> 8-byte (bf16) / 16-byte (fp32) row-major
 // stores and float4 bias/scale/residual reads in the epilogue.
-// Staging: global -> VGPR (16 B/lane, coalesced 128-B rows) -> LDS with a 16-B-chunk XOR
-// swizzle (chunk ^= (row>>1)&7 on 128-B rows: conflict-free for the ds_read_b128 lane groups),
-// double-buffered; the next tile's global loads are issued before the MFMA phase and written to
-// the other LDS buffer after it (one barrier per K-tile).
+// Staging: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip): one wave-instruction lands 8 rows x
+// 128 B = 1 KiB lane-linear in LDS; the bank swizzle (16-B chunk ^= (row>>1)&7, conflict-free for
+// the ds_read_b128 lane groups on 128-B rows) is applied on the per-lane SOURCE address and again on
+// the read (an involution), never on the LDS destination.  Two LDS stages (64 KiB, 2 workgroups/CU):
+// tile t+1 streams in while tile t feeds the MFMAs; one barrier per K-tile.
+// Tile order: XCD-aware (blocks b, b+8, .. share an L2) and grouped 8 m-tiles deep inside each XCD's
+// contiguous run, so the ~64 tiles resident on an XCD share 8 A panels and 8 W panels (3 MiB < 4 MiB L2).
 #include "dod_common.h"
+#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -21,6 +25,77 @@
 #define STAGE_BYTES (2 * BM * BK * 2)   // A + W tile, bf16
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// ---- epilogue, staged through LDS so that HBM sees whole rows ---------------------------------------
+// Phase 1 (stage_acc): a lane owns output row m and its register quads 4 consecutive n: it applies
+// bias / activation / LayerScale (float4 per-n parameter reads) and writes float4s into an fp32 LDS
+// tile [rows][cols] with a row pitch of cols*4 + 16 bytes (conflict-free ds_write_b128).
+// Phase 2 (drain_tile): every wave instruction moves ONE whole tile row: 16 B per lane from LDS, the
+// coalesced fp32 residual / position rows from HBM, and a coalesced store (1 KiB fp32 or 512 B bf16 per
+// instruction) -- instead of 32 rows x 16-B fragments per store instruction straight from the
+// accumulator layout, which made the epilogue cost 2x its HBM time.
+__device__ __forceinline__ void stage_acc(char* sm, int pitch, int row_l, int col_l, const f32x16& a,
+                                          const GemmEpi& e, int n0, int N, int lh) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int nl = col_l + 8 * g + 4 * lh;
+    const int n = n0 + nl;
+    float v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = a[4 * g + t];
+    if (n < N) {
+      if (e.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(e.bias + n);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+      }
+      if (e.act == ACT_GELU) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = gelu_fast(v[t]);
+      } else if (e.act == ACT_RELU) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+      }
+      if (e.scale) {
+        const float4 s4 = *reinterpret_cast<const float4*>(e.scale + n);
+        v[0] *= s4.x; v[1] *= s4.y; v[2] *= s4.z; v[3] *= s4.w;
+      }
+    }
+    *reinterpret_cast<float4*>(sm + row_l * pitch + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// rows of the LDS tile map to global rows through `rowmap` (row_l -> m)
+template <int ROWS, int COLS, int NT, typename RowMap>
+__device__ __forceinline__ void drain_tile(const char* sm, int pitch, const GemmEpi& e, int M, int N, int n0,
+                                           int tid, RowMap rowmap) {
+  constexpr int C4 = COLS / 4;
+#pragma unroll 4
+  for (int idx = tid; idx < ROWS * C4; idx += NT) {
+    const int row_l = idx / C4, c4 = idx - row_l * C4;
+    const int m = rowmap(row_l), n = n0 + 4 * c4;
+    if (m >= M || n >= N) continue;
+    float4 v = *reinterpret_cast<const float4*>(sm + row_l * pitch + c4 * 16);
+    size_t orow = (size_t)m;
+    if (e.rows_per_img > 0) {
+      const int b = m / e.rows_per_img, p = m - b * e.rows_per_img;
+      orow = (size_t)b * e.out_rows_per_img + 1 + p;
+      const float4 p4 = *reinterpret_cast<const float4*>(e.pos + (size_t)(1 + p) * N + n);
+      v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+    }
+    if (e.resid) {
+      const float4 r4 = *reinterpret_cast<const float4*>(e.resid + orow * e.ldr + n);
+      v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+    }
+    if (e.out_f32) {
+      *reinterpret_cast<float4*>(e.out_f32 + orow * e.ldc + n) = v;
+    } else {
+      uint2 o;
+      o.x = pack2bf(v.x, v.y);
+      o.y = pack2bf(v.z, v.w);
+      *reinterpret_cast<uint2*>(e.out_bf16 + orow * e.ldc + n) = o;
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int lda,
                                                         const bf16_t* __restrict__ W, int ldw,
@@ -37,39 +112,49 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
+  int tm, tn;
+  {
+    const int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = bid - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // staging assignment: 4 chunks of A and 4 of W per thread per K-tile
-  const bf16_t* gA[4];
-  const bf16_t* gW[4];
-  int ldsoff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-    int ra = m0 + row; ra = ra < M ? ra : M - 1;
-    int rw = n0 + row; rw = rw < N ? rw : N - 1;
-    gA[i] = A + (size_t)ra * lda + c * 8;
-    gW[i] = W + (size_t)rw * ldw + c * 8;
-    ldsoff[i] = row * 128 + swz128(row, c) * 16;
+  // staging: per K-tile each wave issues 4 LDS-DMA pieces of A and 4 of W (piece = 8 rows x 128 B).
+  // lane -> (row = piece*8 + lane>>3, LDS chunk slot = lane&7); it fetches global chunk slot ^ ((row>>1)&7).
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const bf16_t* gA0; const bf16_t* gA1; const bf16_t* gA2; const bf16_t* gA3;
+  const bf16_t* gW0; const bf16_t* gW1; const bf16_t* gW2; const bf16_t* gW3;
+  {
+    auto src = [&](const bf16_t* base, int ld, int r0, int piece, int lim) {
+      const int rl = piece * 8 + (lane >> 3);
+      int r = r0 + rl; r = r < lim ? r : lim - 1;
+      const int c = (lane & 7) ^ ((rl >> 1) & 7);
+      return base + (size_t)r * ld + c * 8;
+    };
+    const int p0 = wid * 4;
+    gA0 = src(A, lda, m0, p0, M); gA1 = src(A, lda, m0, p0 + 1, M); gA2 = src(A, lda, m0, p0 + 2, M); gA3 = src(A, lda, m0, p0 + 3, M);
+    gW0 = src(W, ldw, n0, p0, N); gW1 = src(W, ldw, n0, p0 + 1, N); gW2 = src(W, ldw, n0, p0 + 2, N); gW3 = src(W, ldw, n0, p0 + 3, N);
   }
-  uint4 ra_[4], rw_[4];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra_[i] = *reinterpret_cast<const uint4*>(gA[i] + k0);
-      rw_[i] = *reinterpret_cast<const uint4*>(gW[i] + k0);
-    }
-  };
-  auto lwrite = [&](int stage) {
-    char* sA = smem + stage * STAGE_BYTES;
-    char* sW = sA + BM * BK * 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(sA + ldsoff[i]) = ra_[i];
-      *reinterpret_cast<uint4*>(sW + ldsoff[i]) = rw_[i];
-    }
-  };
+  const int wbase = __builtin_amdgcn_readfirstlane(wid) * 4096;     // this wave's 4 pieces, wave-uniform
+#define STAGE(stage, k0)                                                                                   \
+  {                                                                                                        \
+    char* sA_ = smem + (stage) * STAGE_BYTES + wbase;                                                      \
+    char* sW_ = sA_ + BM * BK * 2;                                                                         \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (k0)), (lptr_t)(sA_), 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (k0)), (lptr_t)(sA_ + 1024), 16, 0, 0);                \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA2 + (k0)), (lptr_t)(sA_ + 2048), 16, 0, 0);                \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA3 + (k0)), (lptr_t)(sA_ + 3072), 16, 0, 0);                \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sW_), 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW1 + (k0)), (lptr_t)(sW_ + 1024), 16, 0, 0);                \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW2 + (k0)), (lptr_t)(sW_ + 2048), 16, 0, 0);                \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW3 + (k0)), (lptr_t)(sW_ + 3072), 16, 0, 0);                \
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -80,12 +165,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = K / BK;
-  gload(0);
-  lwrite(0);
-  __syncthreads();
+  STAGE(0, 0)
+  __syncthreads();      // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
   const int lr = lane & 31, lh = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if (kt + 1 < nk) STAGE((kt + 1) & 1, (kt + 1) * BK)
     const char* sA = smem + (kt & 1) * STAGE_BYTES;
     const char* sW = sA + BM * BK * 2;
 #pragma unroll
@@ -104,66 +188,273 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) lwrite((kt + 1) & 1);
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns row m, register quads own 4 consecutive n
+  // all ring reads are done (last barrier of the loop); reuse the ring as the fp32 output tile
+  constexpr int PITCH = BN * 4 + 16;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + lr;
-    if (m >= M) continue;
-    size_t orow = (size_t)m;
-    const float* posrow = nullptr;
-    if (e.rows_per_img > 0) {
-      const int b = m / e.rows_per_img, p = m - b * e.rows_per_img;
-      orow = (size_t)b * e.out_rows_per_img + 1 + p;
-      posrow = e.pos + (size_t)(1 + p) * N;
-    }
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 2; ++j)
+      stage_acc(smem, PITCH, wm * 64 + i * 32 + lr, wn * 64 + j * 32, acc[i][j], e, n0, N, lh);
+  __syncthreads();
+  drain_tile<BM, BN, 256>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + row_l; });
+}
+
+// ============================================================================================
+// Large-shape variant: 256x256x32 tile, 512 threads = 8 waves (2 along M x 4 along N), each wave a
+// 128x64 sub-tile = 4x2 32x32x16 accumulators (128 acc VGPRs), ONE workgroup per CU.
+// Why 256x256: the per-CU vector-memory -> LDS path tops out near 70 GB/s (MI355X_MICROARCH "Indexed
+// rows": 66-73 GB/s per CU from L2); a 128x128 tile needs 134 GB/s per CU at MFMA peak, 256x256 needs
+// 67 GB/s.  Staging is LDS-DMA into a FOUR-slot ring of 32-KiB K-tiles (BK = 32: 64-B rows, one piece =
+// 16 rows) with up to THREE K-tiles in flight behind counted s_waitcnt vmcnt(N) and ONE raw s_barrier per
+// K-tile (a __syncthreads() would drain the DMA queue):
+//     wait(tile kt landed: vmcnt(8) leaves tiles kt+1, kt+2 in flight) ; barrier ;
+//     issue tile kt+3 into the slot tile kt-1 just vacated ; 16 MFMAs per wave on tile kt
+// Bank swizzle for 64-B rows: 16-B chunk ^= (row>>2)&3 (four rows share a 256-B bank row); applied on
+// the DMA source address and on the ds_read_b128, conflict-free for the b128 lane groups.
+#define B4M 256
+#define B4N 256
+#define B4K 32
+#define B4_STAGE ((B4M + B4N) * B4K * 2)   // 32 KiB
+#define B4_SLOTS 4
+
+__device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+
+__global__ __launch_bounds__(512) void gemm_bf16_256x256_kernel(const bf16_t* __restrict__ A, int lda,
+                                                                const bf16_t* __restrict__ W, int ldw,
+                                                                int M, int N, int K, GemmEpi e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int tiles_m = (M + B4M - 1) / B4M, tiles_n = (N + B4N - 1) / B4N;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  {
+    const int GM = 4;     // ~32 resident tiles per XCD: 4 A panels x up to 8 W panels
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = bid - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
+  const int m0 = tm * B4M, n0 = tn * B4N;
+
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // per K-tile a wave issues 2 pieces of A and 2 of W; piece = 16 rows x 64 B; lane -> (row = lane>>2, slot = lane&3)
+  const bf16_t* gA0; const bf16_t* gA1; const bf16_t* gW0; const bf16_t* gW1;
+  {
+    auto src = [&](const bf16_t* base, int ld, int r0, int piece, int lim) {
+      const int rl = piece * 16 + (lane >> 2);
+      int r = r0 + rl; r = r < lim ? r : lim - 1;
+      const int c = (lane & 3) ^ ((rl >> 2) & 3);
+      return base + (size_t)r * ld + c * 8;
+    };
+    gA0 = src(A, lda, m0, wid * 2, M); gA1 = src(A, lda, m0, wid * 2 + 1, M);
+    gW0 = src(W, ldw, n0, wid * 2, N); gW1 = src(W, ldw, n0, wid * 2 + 1, N);
+  }
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+#define STAGE4(slot_, k0)                                                                                  \
+  {                                                                                                        \
+    char* sA_ = smem + (slot_) * B4_STAGE + wu * 2048;                                                     \
+    char* sW_ = sA_ + B4M * B4K * 2;                                                                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (k0)), (lptr_t)(sA_), 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (k0)), (lptr_t)(sA_ + 1024), 16, 0, 0);                \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sW_), 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW1 + (k0)), (lptr_t)(sW_ + 1024), 16, 0, 0);                \
+  }
+
+  f32x16 acc[4][2];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * lh;
-        if (n >= N) continue;
-        float v[4];
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = acc[i][j][4 * g + t];
-        if (e.bias) {
-          const float4 b4 = *reinterpret_cast<const float4*>(e.bias + n);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        }
-        if (e.act == ACT_GELU) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) v[t] = gelu_erf(v[t]);
-        } else if (e.act == ACT_RELU) {
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / B4K;
+  const int lr = lane & 31, lh = lane >> 5;
+  STAGE4(0, 0)
+  if (nk > 1) STAGE4(1, B4K)
+  if (nk > 2) STAGE4(2, 2 * B4K)
+  // per-lane LDS read offsets (row * 64 + swizzled chunk * 16) for k-step 0; k-step 1 = chunk + 2 -> xor 32 bytes
+  int offA[4], offW[2];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
-        }
-        if (e.scale) {
-          const float4 s4 = *reinterpret_cast<const float4*>(e.scale + n);
-          v[0] *= s4.x; v[1] *= s4.y; v[2] *= s4.z; v[3] *= s4.w;
-        }
-        if (posrow) {
-          const float4 p4 = *reinterpret_cast<const float4*>(posrow + n);
-          v[0] += p4.x; v[1] += p4.y; v[2] += p4.z; v[3] += p4.w;
-        }
-        if (e.resid) {
-          const float4 r4 = *reinterpret_cast<const float4*>(e.resid + orow * e.ldr + n);
-          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-        }
-        if (e.out_f32) {
-          *reinterpret_cast<float4*>(e.out_f32 + orow * e.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          uint2 o;
-          o.x = pack2bf(v[0], v[1]);
-          o.y = pack2bf(v[2], v[3]);
-          *reinterpret_cast<uint2*>(e.out_bf16 + orow * e.ldc + n) = o;
-        }
-      }
+  for (int i = 0; i < 4; ++i) { const int row = wm * 128 + i * 32 + lr; offA[i] = row * 64 + swz64(row, lh) * 16; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offW[j] = B4M * B4K * 2 + row * 64 + swz64(row, lh) * 16; }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int rem = nk - 1 - kt;
+    if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 3 < nk) STAGE4((kt + 3) & 3, (kt + 3) * B4K)
+    const char* st = smem + (kt & 3) * B4_STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], wf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ (kk * 32)));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ (kk * 32)));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
   }
+  // epilogue: two passes of 128 tile rows (64 from each M-half) through a 128 x 256 fp32 LDS tile
+  constexpr int PITCH = B4N * 4 + 16;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __builtin_amdgcn_s_barrier();          // ring (pass 0) / previous pass's tile fully consumed
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        stage_acc(smem, PITCH, wm * 64 + i * 32 + lr, wn * 64 + j * 32, acc[pass * 2 + i][j], e, n0, N, lh);
+    __syncthreads();
+    drain_tile<128, B4N, 512>(smem, PITCH, e, M, N, n0, tid,
+                              [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+  }
 }
+
+// ============================================================================================
+// Mid variant: 256x128x32 tile, 512 threads = 8 waves (4 along M x 2 along N, 64x64 each), THREE-slot
+// LDS-DMA ring of 24-KiB K-tiles (72 KiB) so that TWO workgroups share a CU: one workgroup's prologue
+// (first-tile latency) and LDS-staged epilogue (store drain) overlap the other's MFMA loop -- with one
+// workgroup per CU those phases run serially and cost ~1/3 of a K=768 GEMM.  Two K-tiles in flight per
+// workgroup behind vmcnt(3) (3 pieces per wave per K-tile), one raw barrier per K-tile.
+#define B5M 256
+#define B5N 128
+#define B5_STAGE ((B5M + B5N) * B4K * 2)   // 24 KiB
+#define B5_SLOTS 3
+
+__global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_kernel(const bf16_t* __restrict__ A, int lda,
+                                                                   const bf16_t* __restrict__ W, int ldw,
+                                                                   int M, int N, int K, GemmEpi e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_m = (M + B5M - 1) / B5M, tiles_n = (N + B5N - 1) / B5N;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  {
+    const int GM = 8;     // ~64 resident tiles per XCD: 8 A panels x 8 W panels
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = bid - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
+  const int m0 = tm * B5M, n0 = tn * B5N;
+
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // per K-tile a wave issues 2 pieces of A and 1 of W; piece = 16 rows x 64 B
+  const bf16_t* gA0; const bf16_t* gA1; const bf16_t* gW0;
+  {
+    auto src = [&](const bf16_t* base, int ld, int r0, int piece, int lim) {
+      const int rl = piece * 16 + (lane >> 2);
+      int r = r0 + rl; r = r < lim ? r : lim - 1;
+      const int c = (lane & 3) ^ ((rl >> 2) & 3);
+      return base + (size_t)r * ld + c * 8;
+    };
+    gA0 = src(A, lda, m0, wid * 2, M); gA1 = src(A, lda, m0, wid * 2 + 1, M);
+    gW0 = src(W, ldw, n0, wid, N);
+  }
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+#define STAGE5(slot_, k0)                                                                                  \
+  {                                                                                                        \
+    char* sA_ = smem + (slot_) * B5_STAGE + wu * 2048;                                                     \
+    char* sW_ = smem + (slot_) * B5_STAGE + B5M * B4K * 2 + wu * 1024;                                     \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (k0)), (lptr_t)(sA_), 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (k0)), (lptr_t)(sA_ + 1024), 16, 0, 0);                \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sW_), 16, 0, 0);                       \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / B4K;
+  const int lr = lane & 31, lh = lane >> 5;
+  STAGE5(0, 0)
+  if (nk > 1) STAGE5(1, B4K)
+  int offA[2], offW[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int row = wm * 64 + i * 32 + lr; offA[i] = row * 64 + swz64(row, lh) * 16; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offW[j] = B5M * B4K * 2 + row * 64 + swz64(row, lh) * 16; }
+
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) {
+      const int ns = slot >= 1 ? slot - 1 : 2;      // (slot + 2) % 3
+      STAGE5(ns, (kt + 2) * B4K)
+    }
+    const char* st = smem + slot * B5_STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ (kk * 32)));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ (kk * 32)));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  // epilogue: two passes of 128 tile rows (32 from each wave row) through a 128 x 128 fp32 LDS tile
+  constexpr int PITCH = B5N * 4 + 16;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      stage_acc(smem, PITCH, wm * 32 + lr, wn * 64 + j * 32, acc[pass][j], e, n0, N, lh);
+    __syncthreads();
+    drain_tile<128, B5N, 512>(smem, PITCH, e, M, N, n0, tid,
+                              [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+  }
+}
+
+// dynamic LDS: the staging ring, or the padded fp32 epilogue tile if larger
+static constexpr int LDS128 = (BM * (BN * 4 + 16)) > 2 * STAGE_BYTES ? (BM * (BN * 4 + 16)) : 2 * STAGE_BYTES;
+static constexpr int LDS5 = (128 * (B5N * 4 + 16)) > B5_SLOTS * B5_STAGE ? (128 * (B5N * 4 + 16)) : B5_SLOTS * B5_STAGE;
+static constexpr int LDS256 = (128 * (B4N * 4 + 16)) > B4_SLOTS * B4_STAGE ? (128 * (B4N * 4 + 16)) : B4_SLOTS * B4_STAGE;
 
 int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K,
                      const GemmEpi& e, hipStream_t s) {
@@ -174,10 +465,27 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
     attr_set = true;
   }
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles), dim3(256), 2 * STAGE_BYTES, s, A, lda, W, ldw, M, N, K, e);
+  const char* force = getenv("DINODET_GEMM_TILE");     // "128" / "256": tuning override
+  // shape heuristic (measured on MI355X, tools/bench_gemm_k.py): 256x128 with two workgroups per CU wins for
+  // the K = 768 shapes of the ViT blocks; 256x256 (one per CU) only for long K; 128x128 for small M.
+  const bool mid = force ? (force[0] == '5') : (M >= 1024 && N >= 128 && K < 2048);
+  const bool big = force ? (force[0] == '2') : (M >= 1024 && N >= 256 && K >= 2048);
+  if (mid) {
+    const int tiles = ((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
+    hipLaunchKernelGGL(gemm_bf16_256x128_kernel, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
+  } else if (big) {
+    const int tiles = ((M + B4M - 1) / B4M) * ((N + B4N - 1) / B4N);
+    hipLaunchKernelGGL(gemm_bf16_256x256_kernel, dim3(tiles), dim3(512), LDS256, s, A, lda, W, ldw, M, N, K, e);
+  } else {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles), dim3(256), LDS128, s, A, lda, W, ldw, M, N, K, e);
+  }
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

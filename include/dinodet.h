@@ -148,6 +148,9 @@ int dod_op_pos_resize(const float* pos_in, int G, int gh, int gw, int D, float* 
 int dod_op_im2col(const float* img, int B, int H, int W, int patch, int Kp, void* out, int out_dtype, void* stream);
 
 const char* dod_version(void);
+/* Devices visible to the HIP runtime libdinodet.so is bound to (<= 0: none / error).  The host uses it to
+ * verify the library shares PyTorch's HIP runtime (pointers and streams cross this ABI). */
+int dod_device_count(void);
 
 #ifdef __cplusplus
 }
