@@ -25,7 +25,86 @@ __device__ __forceinline__ int vswz(int row, int chunk) { return chunk ^ (((row 
 
 typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
 
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+// One K/V tile (64 keys) for one wave (32 query rows on the lanes).  TAIL masks keys >= N (last tile only,
+// so the full tiles carry no compare/select).  Softmax in the exp2 domain with the scale folded into one FMA:
+//   p = exp2(s*c - m*c), m = running max of the raw scores (c > 0).
+template <bool TAIL>
+__device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const bf16x8 (&qf)[4], f32x16 (&o)[2],
+                                          float& m_run, float& l_run, float c, int kbase, int N,
+                                          int lr, int lh, int g16, int tq, int tp) {
+  f32x16 s[2];
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int row = kb * 32 + lr;
+    const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(sK + row * 128 + kswz(row, lh) * 16);
+    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[0], zero, 0, 0, 0);   // C = inline 0: no zeroing moves
+#pragma unroll
+    for (int t = 1; t < 4; ++t) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + row * 128 + kswz(row, 2 * t + lh) * 16);
+      s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], s[kb], 0, 0, 0);
+    }
+  }
+  if (TAIL) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= N) s[kb][r] = -INFINITY;
+      }
+  }
+  float mx = s[0][0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float m_new = fmaxf(m_run, mx * c);            // scaled (exp2-domain) running max
+  const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+  m_run = m_new;
+  const float nm = -m_new;
+  f32x16 p0, p1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    p0[r] = __builtin_amdgcn_exp2f(fmaf(s[0][r], c, nm));
+    p1[r] = __builtin_amdgcn_exp2f(fmaf(s[1][r], c, nm));
+  }
+  const f32x16 ps = p0 + p1;
+  const float lsum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])) +
+                     (((ps[8] + ps[9]) + (ps[10] + ps[11])) + ((ps[12] + ps[13]) + (ps[14] + ps[15])));
+  l_run = fmaf(l_run, alpha, lsum);   // per-half partial; the halves are combined once at the end
+  o[0] *= alpha;
+  o[1] *= alpha;
+  // P^T fragments: accumulator registers 8u..8u+7 of key block kb are the B operand of k-step 2kb+u
+  bf16x8 pf[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const f32x16& pp = (s4 >> 1) ? p1 : p0;
+    const int u = (s4 & 1) * 8;
+    uint4 pk;
+    pk.x = pack2bf(pp[u + 0], pp[u + 1]);
+    pk.y = pack2bf(pp[u + 2], pp[u + 3]);
+    pk.z = pack2bf(pp[u + 4], pp[u + 5]);
+    pk.w = pack2bf(pp[u + 6], pp[u + 7]);
+    pf[s4] = __builtin_bit_cast(bf16x8, pk);
+  }
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    const int col = db * 32 + 16 * (g16 & 1) + 4 * tp;     // first of this lane's 4 source columns
+    const int chunk = col >> 3, inb = (col & 7) * 2;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int r1 = 16 * s4 + 4 * lh + tq, r2 = r1 + 8;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sV + r1 * 128 + vswz(r1, chunk) * 16 + inb));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sV + r2 * 128 + vswz(r2, chunk) * 16 + inb));
+      const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s4], o[db], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                         int N, int heads, float scale_log2e) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * AT_KV * 128];   // [stage][K|V][64 rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -79,83 +158,13 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
   AT_GLOAD(0)
   AT_LWRITE(0)
   __syncthreads();
+  const int nfull = N / AT_KV;                 // tiles without a masked key
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) AT_GLOAD(kt + 1)
     const char* sK = smem + (kt & 1) * (2 * AT_KV * 128);
     const char* sV = sK + AT_KV * 128;
-
-    // ---- S^T = K Q^T : two 32-key blocks
-    f32x16 s[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int row = kb * 32 + lr;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + row * 128 + kswz(row, 2 * t + lh) * 16);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], s[kb], 0, 0, 0);
-      }
-    }
-    // ---- online softmax; lane = query, registers = keys (r&3)+8(r>>2)+4 lh (+32 kb)
-    const bool tail = (kt + 1) * AT_KV > N;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[kb][r] * scale_log2e;
-        if (tail) {
-          const int key = kt * AT_KV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= N) v = -INFINITY;
-        }
-        s[kb][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float lsum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-        s[kb][r] = p;
-        lsum += p;
-      }
-    l_run = l_run * alpha + lsum;   // per-half partial; halves combined once at the end
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-
-    // ---- P^T fragments: accumulator registers 8u..8u+7 of block kb are the B operand of k-step 2kb+u
-    bf16x8 pf[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int kb = s4 >> 1, u = (s4 & 1) * 8;
-      uint32_t w[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = pack2bf(s[kb][u + 2 * j], s[kb][u + 2 * j + 1]);
-      uint4 pk = make_uint4(w[0], w[1], w[2], w[3]);
-      pf[s4] = __builtin_bit_cast(bf16x8, pk);
-    }
-    // ---- O^T += V^T P^T
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const int col = db * 32 + 16 * (g16 & 1) + 4 * tp;     // first of this lane's 4 source columns
-      const int chunk = col >> 3, inb = (col & 7) * 2;
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int r1 = 16 * s4 + 4 * lh + tq, r2 = r1 + 8;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-            (lds_bf16x4_ptr)(sV + r1 * 128 + vswz(r1, chunk) * 16 + inb));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-            (lds_bf16x4_ptr)(sV + r2 * 128 + vswz(r2, chunk) * 16 + inb));
-        const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s4], o[db], 0, 0, 0);
-      }
-    }
+    if (kt < nfull) attn_tile<false>(sK, sV, qf, o, m_run, l_run, scale_log2e, kt * AT_KV, N, lr, lh, g16, tq, tp);
+    else attn_tile<true>(sK, sV, qf, o, m_run, l_run, scale_log2e, kt * AT_KV, N, lr, lh, g16, tq, tp);
     if (kt + 1 < nkt) AT_LWRITE((kt + 1) & 1)
     __syncthreads();
   }
