@@ -185,8 +185,15 @@ def main():
     peak = PEAK_BF16 if a.precision == "bf16" else PEAK_F32
     d = prof[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) if d["ms"] > 0 else 0.0
-    roof = {"bound": "mfma", "kernel": dom + "_kernel", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-            "frac": ach / peak, "traffic": None,
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if a.workload == "vitb518" and a.precision == "bf16" and B_local == 64 and os.path.exists(tj):
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (not measurable live)
+        tdat = json.load(open(tj))
+        traffic, traffic_src = tdat["gemm_bf16_avg_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+    roof = {"bound": "mfma", "kernel": "gemm_bf16_256x128/256x256_kernel (all bf16 MFMA GEMM launches of the step)" if a.precision == "bf16" else "gemm_f32_kernel",
+            "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+            "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": d["launches"] // nprof, "avg_launch_us": 1e3 * d["ms"] / max(1, d["launches"]),
             "flops_per_launch_avg": d["flops"] / max(1, d["launches"]),
             "other_kernels": {k: {"ms_per_step": v["ms"] / nprof, "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None}

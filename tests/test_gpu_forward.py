@@ -154,7 +154,9 @@ def test_bf16_vitb_vs_bf16_faithful_oracle_and_fp32_reference(G, R, B):
     assert rel_err(emb.cpu().numpy(), taps["embeddings"].numpy()) < 1e-5
     # one bf16 ulp is 2^-8 = 3.9e-3 relative: a handful of operand roundings flip between the two evaluations
     assert rel_err(blk0.cpu().numpy(), taps["block0"].numpy()) < 4e-3
-    assert rel_l2(blk0.cpu().numpy(), taps["block0"].numpy()) < 1e-3
+    # a difference d entering a bf16 re-quantisation leaves it as ~sqrt(d * 2^-8): 1e-4 (flash-vs-global-max P
+    # rounding) -> 6e-4 (ctx) -> ~1.5e-3 after the MLP's two roundings
+    assert rel_l2(blk0.cpu().numpy(), taps["block0"].numpy()) < 3e-3
     f = mem.cpu().numpy()
     e_emu = rel_l2(f, emu["features"].numpy())
     e_f32 = rel_l2(f, f32["features"].numpy())
