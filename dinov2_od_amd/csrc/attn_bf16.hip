@@ -5,8 +5,8 @@
 // Layout: qkv is the fused-QKV GEMM output [B*N, 3*D] bf16 (q | k | v column blocks, head h at
 // columns h*64..h*64+63 of each block); ctx is [B*N, D] bf16.
 // One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows.
-// K/V tiles of 64 keys are staged global -> VGPR -> LDS (double-buffered, next tile's loads issued
-// before the MFMA phase, written after it; one barrier per tile).
+// K/V tiles of 64 keys stream by LDS-DMA into a 3-slot ring (48 KiB, 3 workgroups/CU), two tiles in flight behind
+// a counted s_waitcnt vmcnt(4) and one raw s_barrier per tile.
 // "Swapped" products keep the query on the MFMA lane so the softmax row state (m, l) is per-lane:
 //   S^T = K Q^T   (A = K tile rows from LDS via ds_read_b128, B = Q fragments held in registers)
 //   O^T += V^T P^T (A = V^T via ds_read_b64_tr_b16 from the row-major V tile, B = the S^T accumulator
@@ -89,24 +89,44 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     pk.w = pack2bf(pp[u + 6], pp[u + 7]);
     pf[s4] = __builtin_bit_cast(bf16x8, pk);
   }
+  // V^T fragments by ds_read_b64_tr_b16 in inline asm: the builtin form makes hipcc wait vmcnt(0) (it treats the
+  // read as aliasing the pending LDS-DMA writes), which would drain the K/V ring every tile.  Eight reads + their
+  // lgkmcnt wait form ONE statement (cdna guide 5.7 item 1, form i).  Rows 16*s4 (+8) of a lane's address differ
+  // only by immediates because the V swizzle depends on row bit 1 alone.
+  {
+    const int rowb = 4 * lh + tq;
+    const int col0 = 16 * (g16 & 1) + 4 * tp;
+    const int chunk0 = col0 >> 3, inb = (col0 & 7) * 2;
+    const unsigned vaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)sV;
+    const unsigned a0 = vaddr + rowb * 128 + vswz(rowb, chunk0) * 16 + inb;        // d-block 0
+    const unsigned a1 = vaddr + rowb * 128 + vswz(rowb, chunk0 + 4) * 16 + inb;    // d-block 1
 #pragma unroll
-  for (int db = 0; db < 2; ++db) {
-    const int col = db * 32 + 16 * (g16 & 1) + 4 * tp;     // first of this lane's 4 source columns
-    const int chunk = col >> 3, inb = (col & 7) * 2;
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int r1 = 16 * s4 + 4 * lh + tq, r2 = r1 + 8;
-      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sV + r1 * 128 + vswz(r1, chunk) * 16 + inb));
-      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sV + r2 * 128 + vswz(r2, chunk) * 16 + inb));
-      const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s4], o[db], 0, 0, 0);
+    for (int db = 0; db < 2; ++db) {
+      bf16x4 v0, v1, v2, v3, v4, v5, v6, v7;
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %8\n\t"
+          "ds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+          "ds_read_b64_tr_b16 %2, %8 offset:2048\n\t"
+          "ds_read_b64_tr_b16 %3, %8 offset:3072\n\t"
+          "ds_read_b64_tr_b16 %4, %8 offset:4096\n\t"
+          "ds_read_b64_tr_b16 %5, %8 offset:5120\n\t"
+          "ds_read_b64_tr_b16 %6, %8 offset:6144\n\t"
+          "ds_read_b64_tr_b16 %7, %8 offset:7168\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+          : "v"(db ? a1 : a0)
+          : "memory");
+      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7), pf[0], o[db], 0, 0, 0);
+      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(v2, v3, 0, 1, 2, 3, 4, 5, 6, 7), pf[1], o[db], 0, 0, 0);
+      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(v4, v5, 0, 1, 2, 3, 4, 5, 6, 7), pf[2], o[db], 0, 0, 0);
+      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(v6, v7, 0, 1, 2, 3, 4, 5, 6, 7), pf[3], o[db], 0, 0, 0);
     }
   }
 }
 
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                         int N, int heads, float scale_log2e) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * AT_KV * 128];   // [stage][K|V][64 rows][128 B]
+  __shared__ __attribute__((aligned(16))) char smem[3 * 2 * AT_KV * 128];   // [slot][K|V][64 rows][128 B] = 48 KiB
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int D = heads * 64, ld = 3 * D;
@@ -122,28 +142,34 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
     for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(qp + 16 * t);
   }
+  // Retire the Q loads HERE, before any LDS-DMA is in flight: beside a pending global_load_lds hipcc waits
+  // vmcnt(0) at the first use of an ordinary load's result, which would land inside the tile loop and drain
+  // the DMA ring every iteration.  The empty asm makes the fragments "produced" at this point.
+#pragma unroll
+  for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(qf[t]));
 
-  // staging assignment: 2 chunks of K and 2 of V per thread per tile (rows srow and srow + 32)
-  const int srow = tid >> 3, sc = tid & 7;
-  const bf16_t* kvbase = base + D + h * 64 + sc * 8;
-  const int kls0 = srow * 128 + kswz(srow, sc) * 16;          // (row + 32) has the same swizzle term
-  const int vls0 = srow * 128 + vswz(srow, sc) * 16;
-  uint4 rk0, rk1, rv0, rv1;
-#define AT_GLOAD(kt_)                                                              \
-  {                                                                                \
-    int key0 = (kt_) * AT_KV + srow, key1 = key0 + 32;                             \
-    key0 = key0 < N ? key0 : N - 1; key1 = key1 < N ? key1 : N - 1;                \
-    const bf16_t* p0 = kvbase + (size_t)key0 * ld;                                 \
-    const bf16_t* p1 = kvbase + (size_t)key1 * ld;                                 \
-    rk0 = *reinterpret_cast<const uint4*>(p0); rv0 = *reinterpret_cast<const uint4*>(p0 + D); \
-    rk1 = *reinterpret_cast<const uint4*>(p1); rv1 = *reinterpret_cast<const uint4*>(p1 + D); \
-  }
-#define AT_LWRITE(st_)                                                             \
-  {                                                                                \
-    char* sK_ = smem + (st_) * (2 * AT_KV * 128);                                  \
-    char* sV_ = sK_ + AT_KV * 128;                                                 \
-    *reinterpret_cast<uint4*>(sK_ + kls0) = rk0; *reinterpret_cast<uint4*>(sK_ + kls0 + 4096) = rk1; \
-    *reinterpret_cast<uint4*>(sV_ + vls0) = rv0; *reinterpret_cast<uint4*>(sV_ + vls0 + 4096) = rv1; \
+  // staging: LDS-DMA (global_load_lds_dwordx4) into a 3-slot ring of K/V tiles, two tiles in flight.
+  // One piece = 8 key rows x 128 B; per tile a wave issues 2 pieces of K and 2 of V.  lane -> (row = lane>>3,
+  // LDS chunk slot = lane&7); the swizzle goes on the SOURCE chunk (K: ^(row>>1)&7, V: ^((row>>1)&1)<<2).
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const int prow0 = wu * 16 + (lane >> 3), prow1 = prow0 + 8;          // tile rows of this lane's two pieces
+  const int kc0 = ((lane & 7) ^ ((prow0 >> 1) & 7)) * 8, kc1 = ((lane & 7) ^ ((prow1 >> 1) & 7)) * 8;
+  const int vc0 = ((lane & 7) ^ (((prow0 >> 1) & 1) << 2)) * 8, vc1 = ((lane & 7) ^ (((prow1 >> 1) & 1) << 2)) * 8;
+  const bf16_t* kbase = base + D + h * 64;
+#define AT_STAGE(slot_, kt_)                                                                                   \
+  {                                                                                                            \
+    int key0 = (kt_) * AT_KV + prow0, key1 = (kt_) * AT_KV + prow1;                                            \
+    key0 = key0 < N ? key0 : N - 1; key1 = key1 < N ? key1 : N - 1;                                            \
+    const bf16_t* r0 = kbase + (size_t)key0 * ld;                                                              \
+    const bf16_t* r1 = kbase + (size_t)key1 * ld;                                                              \
+    char* sK_ = smem + (slot_) * (2 * AT_KV * 128) + wu * 2048;                                                \
+    char* sV_ = sK_ + AT_KV * 128;                                                                             \
+    __builtin_amdgcn_global_load_lds((gptr_t)(r0 + kc0), (lptr_t)(sK_), 16, 0, 0);                             \
+    __builtin_amdgcn_global_load_lds((gptr_t)(r1 + kc1), (lptr_t)(sK_ + 1024), 16, 0, 0);                      \
+    __builtin_amdgcn_global_load_lds((gptr_t)(r0 + D + vc0), (lptr_t)(sV_), 16, 0, 0);                         \
+    __builtin_amdgcn_global_load_lds((gptr_t)(r1 + D + vc1), (lptr_t)(sV_ + 1024), 16, 0, 0);                  \
   }
 
   f32x16 o[2];
@@ -155,18 +181,24 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
   const int g16 = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
 
   const int nkt = (N + AT_KV - 1) / AT_KV;
-  AT_GLOAD(0)
-  AT_LWRITE(0)
-  __syncthreads();
   const int nfull = N / AT_KV;                 // tiles without a masked key
+  AT_STAGE(0, 0)
+  if (nkt > 1) AT_STAGE(1, 1)
+  int slot = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) AT_GLOAD(kt + 1)
-    const char* sK = smem + (kt & 1) * (2 * AT_KV * 128);
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // tile kt landed, tile kt+1 may fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nkt) {
+      const int ns = slot >= 1 ? slot - 1 : 2;      // (slot + 2) % 3: the slot tile kt-1 just vacated
+      AT_STAGE(ns, kt + 2)
+    }
+    const char* sK = smem + slot * (2 * AT_KV * 128);
     const char* sV = sK + AT_KV * 128;
     if (kt < nfull) attn_tile<false>(sK, sV, qf, o, m_run, l_run, scale_log2e, kt * AT_KV, N, lr, lh, g16, tq, tp);
     else attn_tile<true>(sK, sV, qf, o, m_run, l_run, scale_log2e, kt * AT_KV, N, lr, lh, g16, tq, tp);
-    if (kt + 1 < nkt) AT_LWRITE((kt + 1) & 1)
-    __syncthreads();
+    slot = slot == 2 ? 0 : slot + 1;
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -60,6 +61,11 @@ struct dod_handle {
   struct ProfRec { hipEvent_t a, b; int cls; double flops; };
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> evpool;
+  // two-way batch split on internal streams (dod_forward): kernels of the two half-batches overlap each
+  // other's tails / prologues / epilogues
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
+  int nsplit = -1;
 };
 
 namespace {
@@ -587,6 +593,8 @@ void dod_destroy(dod_handle* h) {
   if (!h) return;
   for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : h->evpool) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->join_ev[i]) (void)hipEventDestroy(h->join_ev[i]); }
+  if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   for (void* p : h->owned) (void)hipFree(p);
   delete h;
 }
@@ -619,7 +627,10 @@ size_t dod_workspace_bytes(const dod_handle* h, int B, int H, int W) {
   Carver c(nullptr);
   carve_backbone(h, c, B, N, nullptr);
   carve_decoder(h, c, B, N, nullptr, false);
-  return c.off + 256;
+  Carver c2(nullptr);     // two-way split layout (dod_forward)
+  const int Bh[2] = {B / 2, B - B / 2};
+  for (int i = 0; i < 2; ++i) if (Bh[i] > 0) { carve_backbone(h, c2, Bh[i], N, nullptr); carve_decoder(h, c2, Bh[i], N, nullptr, false); }
+  return (c.off > c2.off ? c.off : c2.off) + 256;
 }
 
 size_t dod_decoder_workspace_bytes(const dod_handle* h, int B, int N) {
@@ -637,19 +648,59 @@ int dod_set_tap(dod_handle* h, int stage, float* dst) {
 
 static void* align_ws(void* p) { return (void*)(((uintptr_t)p + 255) & ~(uintptr_t)255); }
 
+static int split_setup(dod_handle* h) {
+  if (h->nsplit < 0) {
+    const char* e = getenv("DINODET_STREAMS");
+    h->nsplit = e ? atoi(e) : 2;
+    if (h->nsplit != 2) h->nsplit = 1;
+  }
+  if (h->nsplit == 2 && !h->side[0]) {
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(h, hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+      HIPCHK(h, hipEventCreateWithFlags(&h->join_ev[i], hipEventDisableTiming));
+    }
+    HIPCHK(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  }
+  return DOD_OK;
+}
+
 int dod_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* det, void* workspace, size_t wsb, void* stream) {
   int rc;
   if (!check_common(h, B, H, W, &rc)) return rc;
   if (!pixels || !det || !workspace) return fail(h, DOD_ERR_INVALID, "null buffer");
   if (wsb < dod_workspace_bytes(h, B, H, W)) return fail(h, DOD_ERR_STATE, "workspace too small: %zu < %zu", wsb, dod_workspace_bytes(h, B, H, W));
   const int N = dod_num_tokens(h, H, W);
-  Carver c(align_ws(workspace));
-  BbWS bw; DecWS dw;
-  carve_backbone(h, c, B, N, &bw);
-  carve_decoder(h, c, B, N, &dw, false);
   hipStream_t s = (hipStream_t)stream;
-  rc = backbone_impl(h, pixels, B, H, W, bw, nullptr, true, s); if (rc) return rc;
-  return decoder_impl(h, bw.mem, B, N, dw, det, s);
+  rc = split_setup(h); if (rc) return rc;
+  const bool split = h->nsplit == 2 && B >= 8 && h->taps.empty();
+  if (!split) {
+    Carver c(align_ws(workspace));
+    BbWS bw; DecWS dw;
+    carve_backbone(h, c, B, N, &bw);
+    carve_decoder(h, c, B, N, &dw, false);
+    rc = backbone_impl(h, pixels, B, H, W, bw, nullptr, true, s); if (rc) return rc;
+    return decoder_impl(h, bw.mem, B, N, dw, det, s);
+  }
+  // Images are independent: run the two half-batches on two internal streams forked from / joined to the
+  // caller's stream (capturable: the fork/join events become graph edges).
+  rc = prepare_impl(h, H, W, s); if (rc) return rc;
+  const int Bh[2] = {B / 2, B - B / 2};
+  Carver c(align_ws(workspace));
+  HIPCHK(h, hipEventRecord(h->fork_ev, s));
+  const size_t det_stride = (size_t)h->cfg.num_queries * (h->cfg.num_classes + 4);
+  int b0 = 0;
+  for (int i = 0; i < 2; ++i) {
+    BbWS bw; DecWS dw;
+    carve_backbone(h, c, Bh[i], N, &bw);
+    carve_decoder(h, c, Bh[i], N, &dw, false);
+    HIPCHK(h, hipStreamWaitEvent(h->side[i], h->fork_ev, 0));
+    rc = backbone_impl(h, pixels + (size_t)b0 * 3 * H * W, Bh[i], H, W, bw, nullptr, true, h->side[i]); if (rc) return rc;
+    rc = decoder_impl(h, bw.mem, Bh[i], N, dw, det + (size_t)b0 * det_stride, h->side[i]); if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->join_ev[i], h->side[i]));
+    b0 += Bh[i];
+  }
+  for (int i = 0; i < 2; ++i) HIPCHK(h, hipStreamWaitEvent(s, h->join_ev[i], 0));
+  return DOD_OK;
 }
 
 int dod_backbone_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* features, void* workspace, size_t wsb, void* stream) {

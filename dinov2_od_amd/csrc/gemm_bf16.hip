@@ -34,47 +34,45 @@ __device__ __forceinline__ int swz128(int row, int chunk) { return chunk ^ ((row
 // coalesced fp32 residual / position rows from HBM, and a coalesced store (1 KiB fp32 or 512 B bf16 per
 // instruction) -- instead of 32 rows x 16-B fragments per store instruction straight from the
 // accumulator layout, which made the epilogue cost 2x its HBM time.
-__device__ __forceinline__ void stage_acc(char* sm, int pitch, int row_l, int col_l, const f32x16& a,
-                                          const GemmEpi& e, int n0, int N, int lh) {
+__device__ __forceinline__ void stage_acc(char* sm, int pitch, int row_l, int col_l, const f32x16& a, int lh) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int nl = col_l + 8 * g + 4 * lh;
-    const int n = n0 + nl;
-    float v[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = a[4 * g + t];
-    if (n < N) {
-      if (e.bias) {
-        const float4 b4 = *reinterpret_cast<const float4*>(e.bias + n);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-      }
-      if (e.act == ACT_GELU) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = gelu_fast(v[t]);
-      } else if (e.act == ACT_RELU) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
-      }
-      if (e.scale) {
-        const float4 s4 = *reinterpret_cast<const float4*>(e.scale + n);
-        v[0] *= s4.x; v[1] *= s4.y; v[2] *= s4.z; v[3] *= s4.w;
-      }
-    }
-    *reinterpret_cast<float4*>(sm + row_l * pitch + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(sm + row_l * pitch + nl * 4) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
   }
+}
+
+// Per-thread epilogue parameters: with COLS/4 dividing the thread count, a thread drains the SAME four
+// columns of every row it visits, so bias / LayerScale are two float4 registers loaded once per tile.
+struct ColParams { float4 bias, scale; };
+template <int COLS>
+__device__ __forceinline__ ColParams load_col_params(const GemmEpi& e, int n0, int N, int tid) {
+  ColParams c;
+  const int n = n0 + 4 * (tid % (COLS / 4));
+  const bool ok = n < N;
+  c.bias = (e.bias && ok) ? *reinterpret_cast<const float4*>(e.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  c.scale = (e.scale && ok) ? *reinterpret_cast<const float4*>(e.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+  return c;
 }
 
 // rows of the LDS tile map to global rows through `rowmap` (row_l -> m)
 template <int ROWS, int COLS, int NT, typename RowMap>
-__device__ __forceinline__ void drain_tile(const char* sm, int pitch, const GemmEpi& e, int M, int N, int n0,
-                                           int tid, RowMap rowmap) {
+__device__ __forceinline__ void drain_tile(const char* sm, int pitch, const GemmEpi& e, const ColParams& cp, int M, int N,
+                                           int n0, int tid, RowMap rowmap) {
   constexpr int C4 = COLS / 4;
-#pragma unroll 4
-  for (int idx = tid; idx < ROWS * C4; idx += NT) {
-    const int row_l = idx / C4, c4 = idx - row_l * C4;
-    const int m = rowmap(row_l), n = n0 + 4 * c4;
-    if (m >= M || n >= N) continue;
+  static_assert(NT % C4 == 0, "a thread must keep its column group");
+  const int c4 = tid % C4;
+  const int n = n0 + 4 * c4;
+  if (n >= N) return;
+#pragma unroll
+  for (int row_l = tid / C4; row_l < ROWS; row_l += NT / C4) {
+    const int m = rowmap(row_l);
+    if (m >= M) continue;
     float4 v = *reinterpret_cast<const float4*>(sm + row_l * pitch + c4 * 16);
+    v.x += cp.bias.x; v.y += cp.bias.y; v.z += cp.bias.z; v.w += cp.bias.w;
+    if (e.act == ACT_GELU) { v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w); }
+    else if (e.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    v.x *= cp.scale.x; v.y *= cp.scale.y; v.z *= cp.scale.z; v.w *= cp.scale.w;
     size_t orow = (size_t)m;
     if (e.rows_per_img > 0) {
       const int b = m / e.rows_per_img, p = m - b * e.rows_per_img;
@@ -197,9 +195,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      stage_acc(smem, PITCH, wm * 64 + i * 32 + lr, wn * 64 + j * 32, acc[i][j], e, n0, N, lh);
+      stage_acc(smem, PITCH, wm * 64 + i * 32 + lr, wn * 64 + j * 32, acc[i][j], lh);
+  const ColParams cp = load_col_params<BN>(e, n0, N, tid);
   __syncthreads();
-  drain_tile<BM, BN, 256>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + row_l; });
+  drain_tile<BM, BN, 256>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m0 + row_l; });
 }
 
 // ============================================================================================
@@ -317,6 +316,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256x256_kernel(const bf16_t* __
   }
   // epilogue: two passes of 128 tile rows (64 from each M-half) through a 128 x 256 fp32 LDS tile
   constexpr int PITCH = B4N * 4 + 16;
+  const ColParams cp = load_col_params<B4N>(e, n0, N, tid);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __builtin_amdgcn_s_barrier();          // ring (pass 0) / previous pass's tile fully consumed
@@ -325,9 +325,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_256x256_kernel(const bf16_t* __
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        stage_acc(smem, PITCH, wm * 64 + i * 32 + lr, wn * 64 + j * 32, acc[pass * 2 + i][j], e, n0, N, lh);
+        stage_acc(smem, PITCH, wm * 64 + i * 32 + lr, wn * 64 + j * 32, acc[pass * 2 + i][j], lh);
     __syncthreads();
-    drain_tile<128, B4N, 512>(smem, PITCH, e, M, N, n0, tid,
+    drain_tile<128, B4N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
                               [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
   }
 }
@@ -343,6 +343,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_256x256_kernel(const bf16_t* __
 #define B5_STAGE ((B5M + B5N) * B4K * 2)   // 24 KiB
 #define B5_SLOTS 3
 
+// ABL (tuning only, tools/bench_gemm_k.py with DINODET_GEMM_ABL): 0 = real kernel; 1 = skip the MFMAs;
+// 2 = skip the LDS fragment reads; 3 = skip the LDS-DMA staging after the prologue.  Outputs are wrong for ABL != 0.
+template <int ABL>
 __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_kernel(const bf16_t* __restrict__ A, int lda,
                                                                    const bf16_t* __restrict__ W, int ldw,
                                                                    int M, int N, int K, GemmEpi e) {
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_kernel(const bf16_t*
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + 2 < nk) {
+    if (kt + 2 < nk && ABL != 3) {
       const int ns = slot >= 1 ? slot - 1 : 2;      // (slot + 2) % 3
       STAGE5(ns, (kt + 2) * B4K)
     }
@@ -424,36 +427,160 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_kernel(const bf16_t*
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[2], wf[2];
+      if (ABL == 2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ (kk * 32)));
+        for (int i = 0; i < 2; ++i) { af[i] = __builtin_bit_cast(bf16x8, make_uint4(kt, lane, i, kk)); wf[i] = af[i]; asm volatile("" : "+v"(af[i]), "+v"(wf[i])); }
+      } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ (kk * 32)));
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ (kk * 32)));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ (kk * 32)));
+      }
+      if (ABL == 1) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(af[i]), "v"(wf[i]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
     }
     slot = slot == 2 ? 0 : slot + 1;
   }
   // epilogue: two passes of 128 tile rows (32 from each wave row) through a 128 x 128 fp32 LDS tile
   constexpr int PITCH = B5N * 4 + 16;
+  const ColParams cp = load_col_params<B5N>(e, n0, N, tid);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      stage_acc(smem, PITCH, wm * 32 + lr, wn * 64 + j * 32, acc[pass][j], e, n0, N, lh);
+      stage_acc(smem, PITCH, wm * 32 + lr, wn * 64 + j * 32, acc[pass][j], lh);
     __syncthreads();
-    drain_tile<128, B5N, 512>(smem, PITCH, e, M, N, n0, tid,
+    drain_tile<128, B5N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
                               [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+  }
+}
+
+// ============================================================================================
+// 256x256x64 variant: 128-byte LDS rows (one LDS-DMA piece = 8 rows x 128 B = eight FULL cache lines; the
+// 64-byte rows of the BK=32 kernels make every line two half-line requests -- measured: the staging stream
+// alone runs at ~50 GB/s per CU with 64-B rows, and that stream, not the MFMAs, bounds those kernels).
+// Two 64-KiB stages, one workgroup per CU; tile kt+1 streams in while tile kt (32 MFMAs per wave) computes.
+#define B7_STAGE ((B4M + B4N) * BK * 2)   // 64 KiB
+
+__global__ __launch_bounds__(512) void gemm_bf16_256x256x64_kernel(const bf16_t* __restrict__ A, int lda,
+                                                                   const bf16_t* __restrict__ W, int ldw,
+                                                                   int M, int N, int K, GemmEpi e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int tiles_m = (M + B4M - 1) / B4M, tiles_n = (N + B4N - 1) / B4N;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  {
+    const int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = bid - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
+  const int m0 = tm * B4M, n0 = tn * B4N;
+
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // per K-tile a wave issues 4 pieces of A and 4 of W; piece = 8 rows x 128 B
+  const bf16_t* gA[4];
+  const bf16_t* gW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = (wid * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((rl >> 1) & 7);
+    int ra = m0 + rl; ra = ra < M ? ra : M - 1;
+    int rw = n0 + rl; rw = rw < N ? rw : N - 1;
+    gA[i] = A + (size_t)ra * lda + c * 8;
+    gW[i] = W + (size_t)rw * ldw + c * 8;
+  }
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+#define STAGE7(stage_, k0)                                                                                  \
+  {                                                                                                        \
+    char* sA_ = smem + (stage_) * B7_STAGE + wu * 4096;                                                     \
+    char* sW_ = sA_ + B4M * BK * 2;                                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                      \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gA[i_] + (k0)), (lptr_t)(sA_ + i_ * 1024), 16, 0, 0);       \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gW[i_] + (k0)), (lptr_t)(sW_ + i_ * 1024), 16, 0, 0);       \
+    }                                                                                                      \
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / BK;
+  const int lr = lane & 31, lh = lane >> 5;
+  STAGE7(0, 0)
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 1 < nk) STAGE7((kt + 1) & 1, (kt + 1) * BK)
+    const char* sA = smem + (kt & 1) * B7_STAGE;
+    const char* sW = sA + B4M * BK * 2;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[4], wf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 128 + i * 32 + lr;
+        af[i] = *reinterpret_cast<const bf16x8*>(sA + row * 128 + swz128(row, kk * 2 + lh) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = wn * 64 + j * 32 + lr;
+        wf[j] = *reinterpret_cast<const bf16x8*>(sW + row * 128 + swz128(row, kk * 2 + lh) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  constexpr int PITCH = B4N * 4 + 16;
+  const ColParams cp = load_col_params<B4N>(e, n0, N, tid);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        stage_acc(smem, PITCH, wm * 64 + i * 32 + lr, wn * 64 + j * 32, acc[pass * 2 + i][j], lh);
+    __syncthreads();
+    drain_tile<128, B4N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
+                              [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
   }
 }
 
 // dynamic LDS: the staging ring, or the padded fp32 epilogue tile if larger
 static constexpr int LDS128 = (BM * (BN * 4 + 16)) > 2 * STAGE_BYTES ? (BM * (BN * 4 + 16)) : 2 * STAGE_BYTES;
 static constexpr int LDS5 = (128 * (B5N * 4 + 16)) > B5_SLOTS * B5_STAGE ? (128 * (B5N * 4 + 16)) : B5_SLOTS * B5_STAGE;
+static constexpr int LDS7 = (128 * (B4N * 4 + 16)) > 2 * B7_STAGE ? (128 * (B4N * 4 + 16)) : 2 * B7_STAGE;
 static constexpr int LDS256 = (128 * (B4N * 4 + 16)) > B4_SLOTS * B4_STAGE ? (128 * (B4N * 4 + 16)) : B4_SLOTS * B4_STAGE;
 
 int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K,
@@ -468,8 +595,11 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256x64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS7);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
     attr_set = true;
   }
   const char* force = getenv("DINODET_GEMM_TILE");     // "128" / "256": tuning override
@@ -477,9 +607,17 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   // the K = 768 shapes of the ViT blocks; 256x256 (one per CU) only for long K; 128x128 for small M.
   const bool mid = force ? (force[0] == '5') : (M >= 1024 && N >= 128 && K < 2048);
   const bool big = force ? (force[0] == '2') : (M >= 1024 && N >= 256 && K >= 2048);
-  if (mid) {
+  if (force && force[0] == '7') {
+    const int tiles = ((M + B4M - 1) / B4M) * ((N + B4N - 1) / B4N);
+    hipLaunchKernelGGL(gemm_bf16_256x256x64_kernel, dim3(tiles), dim3(512), LDS7, s, A, lda, W, ldw, M, N, K, e);
+  } else if (mid) {
     const int tiles = ((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
-    hipLaunchKernelGGL(gemm_bf16_256x128_kernel, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
+    const char* ab = getenv("DINODET_GEMM_ABL");
+    const int abl = ab ? atoi(ab) : 0;
+    if (abl == 1) hipLaunchKernelGGL(gemm_bf16_256x128_kernel<1>, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
+    else if (abl == 2) hipLaunchKernelGGL(gemm_bf16_256x128_kernel<2>, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
+    else if (abl == 3) hipLaunchKernelGGL(gemm_bf16_256x128_kernel<3>, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
+    else hipLaunchKernelGGL(gemm_bf16_256x128_kernel<0>, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
   } else if (big) {
     const int tiles = ((M + B4M - 1) / B4M) * ((N + B4N - 1) / B4N);
     hipLaunchKernelGGL(gemm_bf16_256x256_kernel, dim3(tiles), dim3(512), LDS256, s, A, lda, W, ldw, M, N, K, e);
