@@ -672,7 +672,7 @@ int dod_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* 
   const int N = dod_num_tokens(h, H, W);
   hipStream_t s = (hipStream_t)stream;
   rc = split_setup(h); if (rc) return rc;
-  const bool split = h->nsplit == 2 && B >= 8 && h->taps.empty();
+  const bool split = h->nsplit == 2 && B >= 8 && h->taps.empty() && !h->prof_on;   // per-kernel timing wants one stream
   if (!split) {
     Carver c(align_ws(workspace));
     BbWS bw; DecWS dw;

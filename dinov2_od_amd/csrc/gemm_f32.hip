@@ -9,6 +9,7 @@
 // LDS holds both operands k-major ([k][row], stride 66 floats) so the one-float-per-lane MFMA operands
 // are conflict-free ds_read_b32 (lanes 0-31 consecutive rows at k, lanes 32-63 at k+1).
 #include "dod_common.h"
+#include <cstdlib>
 
 #define FBM 64
 #define FBN 64
