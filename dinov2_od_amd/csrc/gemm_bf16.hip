@@ -577,6 +577,110 @@ __global__ __launch_bounds__(512) void gemm_bf16_256x256x64_kernel(const bf16_t*
   }
 }
 
+// ============================================================================================
+// 256x128x32 with v_mfma_f32_16x16x32_bf16 (4x4 accumulators of 16x16 per wave) -- same tile, ring and epilogue as
+// the 32x32x16 kernel; the chip can hold a higher clock on this shape (cdna guide 5.4 rule 28: build both, keep the
+// faster by wall on random data).  Fragment rows are lane&15 and the 16-B k-chunk is lane>>4, so the 64-B-row
+// swizzle becomes chunk ^= ((row>>3)&1)<<1 (conflict-free for the ds_read_b128 lane groups with that lane map).
+__device__ __forceinline__ int swz64m16(int row, int chunk) { return chunk ^ (((row >> 3) & 1) << 1); }
+
+__global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf16_t* __restrict__ A, int lda,
+                                                                       const bf16_t* __restrict__ W, int ldw,
+                                                                       int M, int N, int K, GemmEpi e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_m = (M + B5M - 1) / B5M, tiles_n = (N + B5N - 1) / B5N;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  {
+    const int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = bid - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
+  const int m0 = tm * B5M, n0 = tn * B5N;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const bf16_t* gA0; const bf16_t* gA1; const bf16_t* gW0;
+  {
+    auto src = [&](const bf16_t* base, int ld, int r0, int piece, int lim) {
+      const int rl = piece * 16 + (lane >> 2);
+      int r = r0 + rl; r = r < lim ? r : lim - 1;
+      const int c = swz64m16(rl, lane & 3);
+      return base + (size_t)r * ld + c * 8;
+    };
+    gA0 = src(A, lda, m0, wid * 2, M); gA1 = src(A, lda, m0, wid * 2 + 1, M);
+    gW0 = src(W, ldw, n0, wid, N);
+  }
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = K / B4K;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  STAGE5(0, 0)
+  if (nk > 1) STAGE5(1, B4K)
+  int offA[4], offW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int row = wm * 64 + i * 16 + l15; offA[i] = row * 64 + swz64m16(row, l4) * 16; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int row = wn * 64 + j * 16 + l15; offW[j] = B5M * B4K * 2 + row * 64 + swz64m16(row, l4) * 16; }
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) {
+      const int ns = slot >= 1 ? slot - 1 : 2;
+      STAGE5(ns, (kt + 2) * B4K)
+    }
+    const char* st = smem + slot * B5_STAGE;
+    bf16x8 af[4], wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + offA[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + offW[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  // epilogue: D = W A^T: lane&15 = m within the 16-row block, (lane>>4)*4 + reg = n within the 16-col block
+  constexpr int PITCH = B5N * 4 + 16;
+  const ColParams cp = load_col_params<B5N>(e, n0, N, tid);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row_l = wm * 32 + ii * 16 + l15;
+        const int col = wn * 64 + j * 16 + 4 * l4;
+        const f32x4 a = acc[pass * 2 + ii][j];
+        *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+    __syncthreads();
+    drain_tile<128, B5N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
+                              [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+  }
+}
+
 // dynamic LDS: the staging ring, or the padded fp32 epilogue tile if larger
 static constexpr int LDS128 = (BM * (BN * 4 + 16)) > 2 * STAGE_BYTES ? (BM * (BN * 4 + 16)) : 2 * STAGE_BYTES;
 static constexpr int LDS5 = (128 * (B5N * 4 + 16)) > B5_SLOTS * B5_STAGE ? (128 * (B5N * 4 + 16)) : B5_SLOTS * B5_STAGE;
@@ -596,6 +700,7 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256x64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS7);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_m16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
@@ -603,11 +708,17 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
     attr_set = true;
   }
   const char* force = getenv("DINODET_GEMM_TILE");     // "128" / "256": tuning override
-  // shape heuristic (measured on MI355X, tools/bench_gemm_k.py): 256x128 with two workgroups per CU wins for
-  // the K = 768 shapes of the ViT blocks; 256x256 (one per CU) only for long K; 128x128 for small M.
-  const bool mid = force ? (force[0] == '5') : (M >= 1024 && N >= 128 && K < 2048);
-  const bool big = force ? (force[0] == '2') : (M >= 1024 && N >= 256 && K >= 2048);
-  if (force && force[0] == '7') {
+  // shape heuristic (measured on MI355X, tools/bench_gemm_k.py / bench_ops.py at M = 87680, random data):
+  //   256x128x32 with v_mfma_f32_16x16x32_bf16, two workgroups per CU: QKV 703, out-proj 437, fc1 646, fc2 643 TFLOP/s
+  //   same tile with 32x32x16: 651 / 405 / 607 / 621;  256x256 (one per CU): 624 / 342 / 554 / 619-643
+  // -> the 16x16x32 kernel for every large-M shape; 128x128 for small M (decoder memory at small batch, tests).
+  const bool m16 = force ? (force[0] == '8') : (M >= 1024 && N >= 128);
+  const bool mid = force ? (force[0] == '5') : false;
+  const bool big = force ? (force[0] == '2') : false;
+  if (m16) {
+    const int tiles = ((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
+    hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
+  } else if (force && force[0] == '7') {
     const int tiles = ((M + B4M - 1) / B4M) * ((N + B4N - 1) / B4N);
     hipLaunchKernelGGL(gemm_bf16_256x256x64_kernel, dim3(tiles), dim3(512), LDS7, s, A, lda, W, ldw, M, N, K, e);
   } else if (mid) {
