@@ -586,7 +586,7 @@ __device__ __forceinline__ int swz64m16(int row, int chunk) { return chunk ^ (((
 
 __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf16_t* __restrict__ A, int lda,
                                                                        const bf16_t* __restrict__ W, int ldw,
-                                                                       int M, int N, int K, GemmEpi e) {
+                                                                       int M, int N, int K, GemmEpi e, int GM) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -599,7 +599,6 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
   }
   int tm, tn;
   {
-    const int GM = 8;
     const int per_group = GM * tiles_n;
     const int grp = bid / per_group, first_m = grp * GM;
     const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
@@ -716,8 +715,11 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   const bool mid = force ? (force[0] == '5') : false;
   const bool big = force ? (force[0] == '2') : false;
   if (m16) {
+    // grouped-order depth (m-tiles per group inside an XCD's run), measured: 8 for N = 3072, 4 for 2304, 2 for 768
+    static const char* gme = getenv("DINODET_GEMM_GM");
+    const int gm = gme ? atoi(gme) : (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2));
     const int tiles = ((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
-    hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
+    hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e, gm);
   } else if (force && force[0] == '7') {
     const int tiles = ((M + B4M - 1) / B4M) * ((N + B4N - 1) / B4N);
     hipLaunchKernelGGL(gemm_bf16_256x256x64_kernel, dim3(tiles), dim3(512), LDS7, s, A, lda, W, ldw, M, N, K, e);
