@@ -129,20 +129,26 @@ def main():
     with torch.no_grad():
         out = step()                                # packs weights, sizes workspace, sets func attributes
         torch.cuda.synchronize()
-        use_graph = not a.no_graph and world == 1
+        use_graph = not a.no_graph
         graph = None
         if use_graph:
+            # the forward (all kernels of the hot path) is captured in a hipGraph; at N > 1 the RCCL all-gather
+            # stays an eager call on the same stream right after the replay
             try:
-                static_out = None
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
-                    step()
+                    model.forward_packed(x)
                 torch.cuda.current_stream().wait_stream(s)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    static_out = step()
-                run = graph.replay
+                    static_det = model.forward_packed(x)
+                if world > 1:
+                    def run():
+                        graph.replay()
+                        return ddist.gather_detections_equal(static_det, gathered)
+                else:
+                    run = graph.replay
             except Exception as e:                  # capture unsupported -> eager, say so
                 print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
                 graph, use_graph = None, False

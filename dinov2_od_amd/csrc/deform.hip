@@ -17,14 +17,15 @@
 __global__ __launch_bounds__(256) void deform_sample_kernel(const float* __restrict__ proj, int ldp,
                                                             const float* __restrict__ values, int B, int Q, int N,
                                                             int Hd, int P, int dh, int h, int w,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int proj_shared) {
   const int lane = threadIdx.x & 63;
   const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= (long)B * Q * Hd) return;
   const int hd = (int)(item % Hd);
   const long bq = item / Hd;
   const int b = (int)(bq / Q);
-  const float* pr = proj + (size_t)bq * ldp;
+  // proj_shared: the projections depend on the query only (decoder layer 0: tgt = query_embed for every image)
+  const float* pr = proj + (size_t)(proj_shared ? (bq - (long)b * Q) : bq) * ldp;
   const float refx = sigmoidf_(pr[0]), refy = sigmoidf_(pr[1]);
   const float* off = pr + 2 + hd * P * 2;
   const float* awl = pr + 2 + Hd * P * 2 + hd * P;
@@ -76,11 +77,11 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const float* __restr
 }
 
 int launch_deform_sample(const float* proj, int ldp, const float* values, int B, int Q, int N, int Hd, int P, int dh,
-                         int h, int w, float* out, hipStream_t s) {
+                         int h, int w, float* out, hipStream_t s, int proj_shared) {
   if (P > DF_MAXP || P <= 0 || dh > 128 || dh <= 0) return 2;
   if (h * w != N) return 2;   // the reference raises / re-infers here (deformable_attention.py:76-83)
   const long items = (long)B * Q * Hd;
   hipLaunchKernelGGL(deform_sample_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, proj, ldp, values, B, Q, N,
-                     Hd, P, dh, h, w, out);
+                     Hd, P, dh, h, w, out, proj_shared);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

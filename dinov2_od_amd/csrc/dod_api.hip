@@ -468,7 +468,7 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
   if (dh > 128 || dh % 4) return fail(h, DOD_ERR_INVALID, "decoder head_dim %d unsupported (<=128, multiple of 4)", dh);
   int rc;
   tap(h, 1000, mem_op, bf, (size_t)M * Dd, s);
-  KCHK(h, launch_bcast_rows(h->query, ws.tgt, B, Q, Dd, s));                                                  // K10
+  KCHK(h, launch_bcast_rows(h->query, ws.tgt, 1, Q, Dd, s));                                                  // K10 (image 0; broadcast after layer 0's shared part)
   int fh = 0, fw = 0;
   if (g.use_deformable) {
     spatial_factor(N, &fh, &fw);                                                                                // K16
@@ -482,13 +482,17 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
     tap(h, 2000, ws.values, false, (size_t)M * Dd, s);
   }
   const float sscale = 1.0f / std::sqrt((float)dh);
-  auto self_attn = [&](const DLayer& L) -> int {                                                               // K11
-    int r = linear(h, false, ws.tgt, Dd, L.in_w, Dd, BQ, 3 * Dd, Dd, epi(L.in_b, ws.qkv, nullptr, 3 * Dd), s); if (r) return r;
+  // nb = number of images the query rows are computed for: B, or 1 in layer 0 where tgt = query_embed for every image
+  // (detr_decoder.py:59), so the self-attention block and the sampling projections are image-independent there --
+  // same kernels, same per-row arithmetic, computed once and broadcast (bit-identical to the per-image evaluation).
+  auto self_attn = [&](const DLayer& L, int nb) -> int {                                                       // K11
+    const int rows = nb * Q;
+    int r = linear(h, false, ws.tgt, Dd, L.in_w, Dd, rows, 3 * Dd, Dd, epi(L.in_b, ws.qkv, nullptr, 3 * Dd), s); if (r) return r;
     AttnF32 a; a.q = ws.qkv; a.k = ws.qkv + Dd; a.v = ws.qkv + 2 * Dd; a.o = ws.att; a.ldq = a.ldk = a.ldv = 3 * Dd; a.ldo = Dd;
-    a.Lq = a.Lk = Q; a.B = B; a.heads = Hd; a.dh = dh; a.scale = sscale;
+    a.Lq = a.Lk = Q; a.B = nb; a.heads = Hd; a.dh = dh; a.scale = sscale;
     KCHK(h, launch_attn_f32(a, s));
-    r = linear(h, false, ws.att, Dd, L.out_w, Dd, BQ, Dd, Dd, epi(L.out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s); if (r) return r;
-    KCHK(h, launch_layernorm(ws.t2, nullptr, L.n1w, L.n1b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
+    r = linear(h, false, ws.att, Dd, L.out_w, Dd, rows, Dd, Dd, epi(L.out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s); if (r) return r;
+    KCHK(h, launch_layernorm(ws.t2, nullptr, L.n1w, L.n1b, g.dec_ln_eps, rows, Dd, ws.tgt, nullptr, s));
     return 0;
   };
   auto ffn = [&](const DLayer& L) -> int {                                                                     // K18
@@ -500,17 +504,20 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
   int uniq_idx[64]; { int u = 0; for (int j = 0; j < g.dec_layers && j < 64; ++j) uniq_idx[j] = h->DL[j].vp_alias < 0 ? u++ : -1; }
   for (int j = 0; j < g.dec_layers; ++j) {
     const DLayer& L = h->DL[j];
-    rc = self_attn(L); if (rc) return rc;
+    const bool shared0 = (j == 0 && B > 1);          // layer 0: query rows identical for every image
+    rc = self_attn(L, shared0 ? 1 : B); if (rc) return rc;
     if (g.use_deformable) {
       // K12 + K13 fused small linear, then K15 gather
-      rc = linear(h, false, ws.tgt, Dd, L.cat_w, Dd, BQ, h->ncat, Dd, epi(L.cat_b, ws.proj, nullptr, h->ncat), s); if (rc) return rc;
+      rc = linear(h, false, ws.tgt, Dd, L.cat_w, Dd, shared0 ? Q : BQ, h->ncat, Dd, epi(L.cat_b, ws.proj, nullptr, h->ncat), s); if (rc) return rc;
+      if (shared0) KCHK(h, launch_bcast_rows(ws.tgt, ws.tgt + (size_t)Q * Dd, B - 1, Q, Dd, s));   // rows of image 0 -> images 1..B-1
       const int src = L.vp_alias >= 0 ? L.vp_alias : j;
       const float* vals = ws.values + (size_t)uniq_idx[src] * M * Dd;
-      KCHK(h, launch_deform_sample(ws.proj, h->ncat, vals, B, Q, N, Hd, Pn, dh, fh, fw, ws.samp, s));
+      KCHK(h, launch_deform_sample(ws.proj, h->ncat, vals, B, Q, N, Hd, Pn, dh, fh, fw, ws.samp, s, shared0 ? 1 : 0));
       rc = linear(h, false, ws.samp, Dd, L.op_w, Dd, BQ, Dd, Dd, epi(L.op_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s); if (rc) return rc;   // K17
       KCHK(h, launch_layernorm(ws.t2, nullptr, L.n2w, L.n2b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
     } else {
       // K20: dense cross-attention over all N memory tokens
+      if (shared0) KCHK(h, launch_bcast_rows(ws.tgt, ws.tgt + (size_t)Q * Dd, B - 1, Q, Dd, s));
       rc = linear(h, false, ws.tgt, Dd, L.ca_q_w, Dd, BQ, Dd, Dd, epi(L.ca_q_b, ws.qd, nullptr, Dd), s); if (rc) return rc;
       rc = linear(h, bf, mem_op, Dd, L.ca_kv_w, Dd, M, 2 * Dd, Dd, epi(L.ca_kv_b, ws.kv, nullptr, 2 * Dd), s); if (rc) return rc;
       AttnF32 a; a.q = ws.qd; a.k = ws.kv; a.v = ws.kv + Dd; a.o = ws.att; a.ldq = Dd; a.ldk = a.ldv = 2 * Dd; a.ldo = Dd;

@@ -116,4 +116,4 @@ int launch_bcast_rows(const float* src, float* dst, int B, int rows, int D, hipS
 
 // K12/K13/K15: proj [B*Q, ldp] = [ref logits(2) | offsets(Hd*P*2) | weight logits(Hd*P)], values fp32 [B*N, Dd]
 int launch_deform_sample(const float* proj, int ldp, const float* values, int B, int Q, int N, int Hd, int P, int dh,
-                         int h, int w, float* out, hipStream_t s);
+                         int h, int w, float* out, hipStream_t s, int proj_shared = 0);
