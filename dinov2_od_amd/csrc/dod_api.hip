@@ -27,6 +27,8 @@ struct DLayer {
   float *in_w = nullptr, *in_b = nullptr, *out_w = nullptr, *out_b = nullptr;
   float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr, *n3w = nullptr, *n3b = nullptr;
   float *l1w = nullptr, *l1b = nullptr, *l2w = nullptr, *l2b = nullptr;
+  // bf16x3-split copies [out, 3*in] of the query-side weights (bf16 mode only; see rowops.hip split3_kernel)
+  bf16_t *in_w3 = nullptr, *out_w3 = nullptr, *l1w3 = nullptr, *l2w3 = nullptr, *op_w3 = nullptr, *ca_q_w3 = nullptr, *ca_out_w3 = nullptr;
   // deformable
   float *cat_w = nullptr, *cat_b = nullptr, *op_w = nullptr, *op_b = nullptr, *vp_b = nullptr;
   void* vp_w = nullptr;            // bf16 / fp32
@@ -51,6 +53,7 @@ struct dod_handle {
   float *bpatch = nullptr, *cls = nullptr, *pos = nullptr, *lnfw = nullptr, *lnfb = nullptr, *bproj = nullptr;
   void* Wproj = nullptr;
   std::vector<DLayer> DL;
+  bf16_t* bb0_w3 = nullptr;
   float *query = nullptr, *cls_w = nullptr, *cls_b = nullptr, *bb0_w = nullptr, *bb0_b = nullptr, *bb2_w = nullptr, *bb2_b = nullptr;
   int ncat = 0;
   // position-table cache
@@ -168,6 +171,13 @@ struct Packer {
     if (find(prefix + ".linear.bias")) return copy(prefix + ".linear.bias", {out_f});
     return copy(prefix + ".bias", {out_f});
   }
+  // bf16x3 split weight [rows, 3*cols] (bf16 mode, cols % 64 == 0), else nullptr
+  bf16_t* split_w(const float* src, int rows, int cols) {
+    if (!src || !is_bf16(h) || cols % 64) return nullptr;
+    bf16_t* b = alloc<bf16_t>((size_t)rows * 3 * cols); if (!b) return nullptr;
+    if (launch_split3(src, cols, b, rows, cols, 1, s)) { if (!rc) rc = fail(h, DOD_ERR_HIP, "split3 launch failed"); return nullptr; }
+    return b;
+  }
   // pack fp32 [rows, cols] (ld = cols) into the precision's operand dtype, K padded to cols_pad
   void* pack_operand(const float* src, int rows, int cols, int cols_pad, bool force_f32 = false) {
     if (!src) return nullptr;
@@ -257,6 +267,7 @@ decoder_part:
     h->query = P.copy(dp + "query_embed.weight", {Q, Dd});
     h->cls_w = P.copy(dp + "class_embed.weight", {C, Dd}); h->cls_b = P.copy(dp + "class_embed.bias", {C});
     h->bb0_w = P.copy(dp + "bbox_embed.mlp.0.weight", {Dd / 2, Dd}); h->bb0_b = P.copy(dp + "bbox_embed.mlp.0.bias", {Dd / 2});
+    h->bb0_w3 = P.split_w(h->bb0_w, Dd / 2, Dd);
     h->bb2_w = P.copy(dp + "bbox_embed.mlp.2.weight", {4, Dd / 2}); h->bb2_b = P.copy(dp + "bbox_embed.mlp.2.bias", {4});
     h->ncat = 2 + 3 * Hd * Pn;
     h->DL.resize(c.dec_layers);
@@ -270,6 +281,8 @@ decoder_part:
       L.n3w = P.copy(lp + "norm3.weight", {Dd}); L.n3b = P.copy(lp + "norm3.bias", {Dd});
       L.l1w = P.copy(lp + "linear1.weight", {Fd, Dd}); L.l1b = P.copy(lp + "linear1.bias", {Fd});
       L.l2w = P.copy(lp + "linear2.weight", {Dd, Fd}); L.l2b = P.copy(lp + "linear2.bias", {Dd});
+      L.in_w3 = P.split_w(L.in_w, 3 * Dd, Dd); L.out_w3 = P.split_w(L.out_w, Dd, Dd);
+      L.l1w3 = P.split_w(L.l1w, Fd, Dd); L.l2w3 = P.split_w(L.l2w, Dd, Fd);
       if (c.use_deformable) {
         // one fused small linear: [reference_points_proj (2) | sampling_offsets (Hd*P*2) | attention_weights (Hd*P)]
         const WRef* rw = P.need(lp + "reference_points_proj.weight", {2, Dd});
@@ -287,6 +300,7 @@ decoder_part:
         HIPCHK(h, hipMemcpyAsync(L.cat_b + 2, ob->ptr, (size_t)Hd * Pn * 2 * 4, hipMemcpyDeviceToDevice, s));
         HIPCHK(h, hipMemcpyAsync(L.cat_b + 2 + Hd * Pn * 2, ab->ptr, (size_t)Hd * Pn * 4, hipMemcpyDeviceToDevice, s));
         L.op_w = P.copy(lp + "cross_attn.output_proj.weight", {Dd, Dd}); L.op_b = P.copy(lp + "cross_attn.output_proj.bias", {Dd});
+        L.op_w3 = P.split_w(L.op_w, Dd, Dd);
         // value projection: layers are weight-tied in the reference (deformable_attention.py:284): when the
         // caller registered the same storage for several layers the projection is computed once per forward
         const WRef* vw = P.need(lp + "cross_attn.value_proj.weight", {Dd, Dd});
@@ -308,6 +322,7 @@ decoder_part:
         HIPCHK(h, hipMemcpyAsync(L.ca_q_b, ib->ptr, (size_t)Dd * 4, hipMemcpyDeviceToDevice, s));
         HIPCHK(h, hipMemcpyAsync(L.ca_kv_b, ib->ptr + Dd, (size_t)2 * Dd * 4, hipMemcpyDeviceToDevice, s));
         L.ca_out_w = P.copy(lp + "multihead_attn.out_proj.weight", {Dd, Dd}); L.ca_out_b = P.copy(lp + "multihead_attn.out_proj.bias", {Dd});
+        L.ca_q_w3 = P.split_w(L.ca_q_w, Dd, Dd); L.ca_out_w3 = P.split_w(L.ca_out_w, Dd, Dd);
       }
     }
   }
@@ -327,7 +342,7 @@ struct Carver {
   void* take(size_t bytes) { void* p = base ? base + off : nullptr; off += align_up(bytes); return p; }
 };
 
-struct DecWS { float *tgt, *t2, *att, *samp, *qkv, *proj, *ffn, *hb, *qd; void* mem_op; float* values; float* kv; };
+struct DecWS { float *tgt, *t2, *att, *samp, *qkv, *proj, *ffn, *hb, *qd; void* mem_op; float* values; float* kv; bf16_t* a3; };
 struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; };
 
 size_t carve_decoder(const dod_handle* h, Carver& c, int B, int N, DecWS* w, bool need_mem_op) {
@@ -339,6 +354,7 @@ size_t carve_decoder(const dod_handle* h, Carver& c, int B, int N, DecWS* w, boo
   t.proj = (float*)c.take(BQ * (size_t)(h->ncat > 0 ? h->ncat : 4) * 4);
   t.ffn = (float*)c.take(BQ * (size_t)g.dim_feedforward * 4); t.hb = (float*)c.take(BQ * (Dd / 2) * 4);
   t.qd = (float*)c.take(BQ * Dd * 4);
+  { const size_t kmax = Dd > (size_t)g.dim_feedforward ? Dd : (size_t)g.dim_feedforward; t.a3 = is_bf16(h) ? (bf16_t*)c.take(BQ * 3 * kmax * 2) : nullptr; }
   t.mem_op = need_mem_op ? c.take(M * Dd * esz(h)) : nullptr;
   if (g.use_deformable) {
     int uniq = 0; for (auto& L : h->DL) if (L.vp_alias < 0) ++uniq;
@@ -482,22 +498,30 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
     tap(h, 2000, ws.values, false, (size_t)M * Dd, s);
   }
   const float sscale = 1.0f / std::sqrt((float)dh);
+  // query-side linear: fp32 MFMA kernel, or (bf16 mode, large enough, N % 4 == 0) the bf16x3-split form on the bf16 kernel
+  auto qlinear = [&](const float* A, int K, const float* Wf, const bf16_t* W3, int rows, int Nout, const GemmEpi& e) -> int {
+    if (bf && W3 && ws.a3 && rows >= 1024 && Nout >= 128 && Nout % 4 == 0 && e.ldc % 4 == 0 && e.act != ACT_SIGMOID) {
+      KCHK(h, launch_split3(A, K, ws.a3, rows, K, 0, s));
+      return linear(h, true, ws.a3, 3 * K, W3, 3 * K, rows, Nout, 3 * K, e, s);
+    }
+    return linear(h, false, A, K, Wf, K, rows, Nout, K, e, s);
+  };
   // nb = number of images the query rows are computed for: B, or 1 in layer 0 where tgt = query_embed for every image
   // (detr_decoder.py:59), so the self-attention block and the sampling projections are image-independent there --
   // same kernels, same per-row arithmetic, computed once and broadcast (bit-identical to the per-image evaluation).
   auto self_attn = [&](const DLayer& L, int nb) -> int {                                                       // K11
     const int rows = nb * Q;
-    int r = linear(h, false, ws.tgt, Dd, L.in_w, Dd, rows, 3 * Dd, Dd, epi(L.in_b, ws.qkv, nullptr, 3 * Dd), s); if (r) return r;
+    int r = qlinear(ws.tgt, Dd, L.in_w, L.in_w3, rows, 3 * Dd, epi(L.in_b, ws.qkv, nullptr, 3 * Dd)); if (r) return r;
     AttnF32 a; a.q = ws.qkv; a.k = ws.qkv + Dd; a.v = ws.qkv + 2 * Dd; a.o = ws.att; a.ldq = a.ldk = a.ldv = 3 * Dd; a.ldo = Dd;
     a.Lq = a.Lk = Q; a.B = nb; a.heads = Hd; a.dh = dh; a.scale = sscale;
     KCHK(h, launch_attn_f32(a, s));
-    r = linear(h, false, ws.att, Dd, L.out_w, Dd, rows, Dd, Dd, epi(L.out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s); if (r) return r;
+    r = qlinear(ws.att, Dd, L.out_w, L.out_w3, rows, Dd, epi(L.out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd)); if (r) return r;
     KCHK(h, launch_layernorm(ws.t2, nullptr, L.n1w, L.n1b, g.dec_ln_eps, rows, Dd, ws.tgt, nullptr, s));
     return 0;
   };
   auto ffn = [&](const DLayer& L) -> int {                                                                     // K18
-    int r = linear(h, false, ws.tgt, Dd, L.l1w, Dd, BQ, Fd, Dd, epi(L.l1b, ws.ffn, nullptr, Fd, ACT_RELU), s); if (r) return r;
-    r = linear(h, false, ws.ffn, Fd, L.l2w, Fd, BQ, Dd, Fd, epi(L.l2b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s); if (r) return r;
+    int r = qlinear(ws.tgt, Dd, L.l1w, L.l1w3, BQ, Fd, epi(L.l1b, ws.ffn, nullptr, Fd, ACT_RELU)); if (r) return r;
+    r = qlinear(ws.ffn, Fd, L.l2w, L.l2w3, BQ, Dd, epi(L.l2b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd)); if (r) return r;
     KCHK(h, launch_layernorm(ws.t2, nullptr, L.n3w, L.n3b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
     return 0;
   };
@@ -513,17 +537,17 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
       const int src = L.vp_alias >= 0 ? L.vp_alias : j;
       const float* vals = ws.values + (size_t)uniq_idx[src] * M * Dd;
       KCHK(h, launch_deform_sample(ws.proj, h->ncat, vals, B, Q, N, Hd, Pn, dh, fh, fw, ws.samp, s, shared0 ? 1 : 0));
-      rc = linear(h, false, ws.samp, Dd, L.op_w, Dd, BQ, Dd, Dd, epi(L.op_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s); if (rc) return rc;   // K17
+      rc = qlinear(ws.samp, Dd, L.op_w, L.op_w3, BQ, Dd, epi(L.op_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd)); if (rc) return rc;   // K17
       KCHK(h, launch_layernorm(ws.t2, nullptr, L.n2w, L.n2b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
     } else {
       // K20: dense cross-attention over all N memory tokens
       if (shared0) KCHK(h, launch_bcast_rows(ws.tgt, ws.tgt + (size_t)Q * Dd, B - 1, Q, Dd, s));
-      rc = linear(h, false, ws.tgt, Dd, L.ca_q_w, Dd, BQ, Dd, Dd, epi(L.ca_q_b, ws.qd, nullptr, Dd), s); if (rc) return rc;
+      rc = qlinear(ws.tgt, Dd, L.ca_q_w, L.ca_q_w3, BQ, Dd, epi(L.ca_q_b, ws.qd, nullptr, Dd)); if (rc) return rc;
       rc = linear(h, bf, mem_op, Dd, L.ca_kv_w, Dd, M, 2 * Dd, Dd, epi(L.ca_kv_b, ws.kv, nullptr, 2 * Dd), s); if (rc) return rc;
       AttnF32 a; a.q = ws.qd; a.k = ws.kv; a.v = ws.kv + Dd; a.o = ws.att; a.ldq = Dd; a.ldk = a.ldv = 2 * Dd; a.ldo = Dd;
       a.Lq = Q; a.Lk = N; a.B = B; a.heads = Hd; a.dh = dh; a.scale = sscale;
       KCHK(h, launch_attn_f32(a, s));
-      rc = linear(h, false, ws.att, Dd, L.ca_out_w, Dd, BQ, Dd, Dd, epi(L.ca_out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s); if (rc) return rc;
+      rc = qlinear(ws.att, Dd, L.ca_out_w, L.ca_out_w3, BQ, Dd, epi(L.ca_out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd)); if (rc) return rc;
       KCHK(h, launch_layernorm(ws.t2, nullptr, L.n2w, L.n2b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
     }
     rc = ffn(L); if (rc) return rc;
@@ -531,7 +555,7 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
   }
   // K19 heads -> packed [B, Q, C+4]
   rc = linear(h, false, ws.tgt, Dd, h->cls_w, Dd, BQ, C, Dd, epi(h->cls_b, det, nullptr, C + 4), s); if (rc) return rc;
-  rc = linear(h, false, ws.tgt, Dd, h->bb0_w, Dd, BQ, Dd / 2, Dd, epi(h->bb0_b, ws.hb, nullptr, Dd / 2, ACT_RELU), s); if (rc) return rc;
+  rc = qlinear(ws.tgt, Dd, h->bb0_w, h->bb0_w3, BQ, Dd / 2, epi(h->bb0_b, ws.hb, nullptr, Dd / 2, ACT_RELU)); if (rc) return rc;
   rc = linear(h, false, ws.hb, Dd / 2, h->bb2_w, Dd / 2, BQ, 4, Dd / 2, epi(h->bb2_b, det + C, nullptr, C + 4, ACT_SIGMOID), s); if (rc) return rc;
   return DOD_OK;
 }

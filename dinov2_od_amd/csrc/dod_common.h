@@ -111,6 +111,8 @@ int launch_cast_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 int launch_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, int cols_pad, hipStream_t s);
 // W' = W + alpha * B[out,r] A[r,in]
 int launch_lora_merge(const float* W, const float* A, const float* Bm, float alpha, int out_f, int in_f, int r, float* dst, hipStream_t s);
+// bf16x3 split: fp32 [rows,K] -> bf16 [rows,3K]; mode 0 = [hi|hi|lo] (activations), 1 = [hi|lo|hi] (weights)
+int launch_split3(const float* in, int ld_in, bf16_t* out, int rows, int K, int mode, hipStream_t s);
 // tgt[b][q][:] = query_embed[q][:]
 int launch_bcast_rows(const float* src, float* dst, int B, int rows, int D, hipStream_t s);
 

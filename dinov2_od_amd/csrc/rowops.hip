@@ -241,3 +241,30 @@ int launch_bcast_rows(const float* src, float* dst, int B, int rows, int D, hipS
   hipLaunchKernelGGL(bcast_rows_kernel, dim3(blocks), dim3(256), 0, s, src, dst, B, n);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
+
+// ----------------------------------------------------------------------------- bf16x3 operand split
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): A W^T ~= Ah Wh^T + Ah Wl^T + Al Wh^T (the lo*lo term, 2^-18
+// relative, is dropped).  Written as ONE bf16 GEMM with K' = 3K:  A' = [Ah | Ah | Al],  W' = [Wh | Wl | Wh].
+// Used for the decoder's query-side linears in bf16 mode: ~fp32 accuracy (1e-5) at bf16 MFMA rate / 3 instead of the
+// fp32 MFMA rate (1/16).   mode 0: activation layout [hi | hi | lo];  mode 1: weight layout [hi | lo | hi].
+__global__ void split3_kernel(const float* __restrict__ in, int ld_in, bf16_t* __restrict__ out, int rows, int K, int mode) {
+  const size_t total = (size_t)rows * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / K;
+    const int c = (int)(i - r * K);
+    const float x = in[r * ld_in + c];
+    const bf16_t hi = f2bf(x);
+    const bf16_t lo = f2bf(x - bf2f(hi));
+    bf16_t* o = out + r * 3 * (size_t)K + c;
+    o[0] = hi;
+    o[K] = mode ? lo : hi;
+    o[2 * (size_t)K] = mode ? hi : lo;
+  }
+}
+int launch_split3(const float* in, int ld_in, bf16_t* out, int rows, int K, int mode, hipStream_t s) {
+  const size_t total = (size_t)rows * K;
+  if (total == 0) return 0;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, s, in, ld_in, out, rows, K, mode);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}

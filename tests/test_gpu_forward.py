@@ -201,3 +201,27 @@ def test_module_prefix_and_error_paths(G):
         m(torch.zeros(1, 3, 8, 8, device=G.dev()))          # smaller than one patch
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 3, 224, 224))
+
+
+def test_bf16_decoder_split3_linears_large_batch(G):
+    """bf16 mode, B*Q >= 1024: the decoder's query-side linears run as bf16x3-split GEMMs (A = Ah+Al, W = Wh+Wl,
+    lo*lo dropped) on the bf16 MFMA kernel instead of the fp32 MFMA kernel.  Held to the oracle evaluated with the
+    same bf16 rounding of the memory-side operands; the split itself is ~1e-5 relative."""
+    from dinov2_od_amd.models import DETRDecoder
+    B, Q, Dd, Hd, N = 12, 100, 128, 4, 257
+    dc = cases.dec_cfg(True, Dd, Hd, Q)
+    sd = synth.decoder_state_dict(dc, seed=1, prefix="decoder.")
+    mem = synth.normal(3, "memory.split3", (B, N, Dd), 1.0)
+    want_l, want_b = orc.decoder_forward(sd, dc, torch.from_numpy(mem).to(torch.bfloat16).float(), emulate_bf16=True)
+    outs = {}
+    for prec in ("bf16", "fp32"):
+        m = DETRDecoder(Q, Dd, Hd, dc.num_layers, dc.num_classes, dim_feedforward=dc.dim_feedforward, n_points=dc.n_points,
+                        use_deformable=True, precision=prec)
+        G.load_np_state(m, {k[len("decoder."):]: v for k, v in sd.items()})
+        m = m.to(G.dev()).eval()
+        outs[prec] = m(G.to_gpu(mem))
+        G.sync()
+    assert rel_err(outs["bf16"]["pred_logits"].cpu().numpy(), want_l.numpy()) < 5e-3
+    assert rel_err(outs["bf16"]["pred_boxes"].cpu().numpy(), want_b.numpy()) < 5e-3
+    # and close to the all-fp32 path (difference = bf16 rounding of memory / value_proj weights, amplified by the decoder)
+    assert rel_err(outs["bf16"]["pred_logits"].cpu().numpy(), outs["fp32"]["pred_logits"].cpu().numpy()) < 3e-2
