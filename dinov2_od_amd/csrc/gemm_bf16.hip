@@ -584,6 +584,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_256x256x64_kernel(const bf16_t*
 // swizzle becomes chunk ^= ((row>>3)&1)<<1 (conflict-free for the ds_read_b128 lane groups with that lane map).
 __device__ __forceinline__ int swz64m16(int row, int chunk) { return chunk ^ (((row >> 3) & 1) << 1); }
 
+// tuning only (tools/gemm_timeline.py): when non-null, thread 0 of every workgroup stores
+// {s_memrealtime at start, after the K loop, at exit (stores drained), blockIdx}
+__device__ unsigned long long* g_gemm_stamps = nullptr;
+
 __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf16_t* __restrict__ A, int lda,
                                                                        const bf16_t* __restrict__ W, int ldw,
                                                                        int M, int N, int K, GemmEpi e, int GM) {
@@ -592,6 +596,9 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_m = (M + B5M - 1) / B5M, tiles_n = (N + B5N - 1) / B5N;
   const int nwg = tiles_m * tiles_n;
+  unsigned long long* stamps = g_gemm_stamps;
+  unsigned long long t_start = 0, t_loop = 0;
+  if (stamps) t_start = __builtin_amdgcn_s_memrealtime();
   int bid = blockIdx.x;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -658,6 +665,7 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     slot = slot == 2 ? 0 : slot + 1;
   }
+  if (stamps) t_loop = __builtin_amdgcn_s_memrealtime();
   // epilogue: D = W A^T: lane&15 = m within the 16-row block, (lane>>4)*4 + reg = n within the 16-col block
   constexpr int PITCH = B5N * 4 + 16;
   const ColParams cp = load_col_params<B5N>(e, n0, N, tid);
@@ -678,6 +686,11 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
     drain_tile<128, B5N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
                               [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
   }
+  if (stamps && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* o = stamps + (size_t)blockIdx.x * 4;
+    o[0] = t_start; o[1] = t_loop; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = blockIdx.x;
+  }
 }
 
 // dynamic LDS: the staging ring, or the padded fp32 epilogue tile if larger
@@ -685,6 +698,11 @@ static constexpr int LDS128 = (BM * (BN * 4 + 16)) > 2 * STAGE_BYTES ? (BM * (BN
 static constexpr int LDS5 = (128 * (B5N * 4 + 16)) > B5_SLOTS * B5_STAGE ? (128 * (B5N * 4 + 16)) : B5_SLOTS * B5_STAGE;
 static constexpr int LDS7 = (128 * (B4N * 4 + 16)) > 2 * B7_STAGE ? (128 * (B4N * 4 + 16)) : 2 * B7_STAGE;
 static constexpr int LDS256 = (128 * (B4N * 4 + 16)) > B4_SLOTS * B4_STAGE ? (128 * (B4N * 4 + 16)) : B4_SLOTS * B4_STAGE;
+
+extern "C" int dod_debug_gemm_stamps(void* dev_buf) {
+  unsigned long long* p = (unsigned long long*)dev_buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 4;
+}
 
 int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K,
                      const GemmEpi& e, hipStream_t s) {

@@ -147,6 +147,11 @@ int dod_op_pos_resize(const float* pos_in, int G, int gh, int gw, int D, float* 
 /* img [B,3,H,W] -> cols [B*(H/p)*(W/p), Kp] of out_dtype */
 int dod_op_im2col(const float* img, int B, int H, int W, int patch, int Kp, void* out, int out_dtype, void* stream);
 
+/* Tuning aid: when dev_buf is non-NULL the large bf16 GEMM kernel stores 4 x uint64 per workgroup
+ * {realtime at start, after the K loop, at exit, blockIdx} (100 MHz s_memrealtime); NULL switches it off.
+ * Used by tools/gemm_timeline.py. */
+int dod_debug_gemm_stamps(void* dev_buf);
+
 const char* dod_version(void);
 /* Devices visible to the HIP runtime libdinodet.so is bound to (<= 0: none / error).  The host uses it to
  * verify the library shares PyTorch's HIP runtime (pointers and streams cross this ABI). */
