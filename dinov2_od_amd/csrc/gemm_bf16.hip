@@ -693,10 +693,128 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
   }
 }
 
+// ============================================================================================
+// 256x256x32 with SIXTEEN waves (1024 threads, 4x4 waves of 64x64, 16x16x32 MFMA): one workgroup per CU but four
+// waves per SIMD, so barrier / LDS-latency stalls of one wave are covered by three others (the 8-wave 256x256 kernels
+// above cannot).  Measured motivation (tools/gemm_timeline.py, ablations): the 256x128 kernel runs at 92 % of what the
+// per-CU vector-memory pipe (~48 GB/s) allows for ITS bytes (576 KiB staged + 64 KiB stored per tile at K = 768);
+// a 256x256 tile moves 29 % fewer bytes per FLOP through that pipe.
+// Four-slot ring of 32-KiB K-tiles, three in flight: vmcnt(4) (2 pieces per wave per K-tile), one barrier per K-tile.
+#define B9_STAGE ((B4M + B4N) * B4K * 2)   // 32 KiB
+#define B9_SLOTS 4
+
+template <int ABL>
+__global__ __launch_bounds__(1024) void gemm_bf16_256x256_w16_kernel(const bf16_t* __restrict__ A, int lda,
+                                                                     const bf16_t* __restrict__ W, int ldw,
+                                                                     int M, int N, int K, GemmEpi e, int GM) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int tiles_m = (M + B4M - 1) / B4M, tiles_n = (N + B4N - 1) / B4N;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  {
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = bid - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
+  const int m0 = tm * B4M, n0 = tn * B4N;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // per K-tile a wave issues ONE piece of A and ONE of W (piece = 16 rows x 64 B; 16 pieces per operand)
+  const bf16_t* gA0; const bf16_t* gW0;
+  {
+    auto src = [&](const bf16_t* base, int ld, int r0, int piece, int lim) {
+      const int rl = piece * 16 + (lane >> 2);
+      int r = r0 + rl; r = r < lim ? r : lim - 1;
+      const int c = swz64m16(rl, lane & 3);
+      return base + (size_t)r * ld + c * 8;
+    };
+    gA0 = src(A, lda, m0, wid, M);
+    gW0 = src(W, ldw, n0, wid, N);
+  }
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+#define STAGE9(slot_, k0)                                                                                  \
+  {                                                                                                        \
+    char* sA_ = smem + (slot_) * B9_STAGE + wu * 1024;                                                     \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (k0)), (lptr_t)(sA_), 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sA_ + B4M * B4K * 2), 16, 0, 0);       \
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = K / B4K;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  STAGE9(0, 0)
+  if (nk > 1) STAGE9(1, B4K)
+  if (nk > 2) STAGE9(2, 2 * B4K)
+  int offA[4], offW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int row = wm * 64 + i * 16 + l15; offA[i] = row * 64 + swz64m16(row, l4) * 16; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int row = wn * 64 + j * 16 + l15; offW[j] = B4M * B4K * 2 + row * 64 + swz64m16(row, l4) * 16; }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int rem = nk - 1 - kt;
+    if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 3 < nk && ABL != 3) STAGE9((kt + 3) & 3, (kt + 3) * B4K)
+    const char* st = smem + (kt & 3) * B9_STAGE;
+    bf16x8 af[4], wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + offA[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + offW[j]);
+    if (ABL == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(af[i]), "v"(wf[i]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  // epilogue: two passes of 128 tile rows through a 128 x 256 fp32 LDS tile (pitch +16 B)
+  constexpr int PITCH = B4N * 4 + 16;
+  const ColParams cp = load_col_params<B4N>(e, n0, N, tid);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row_l = wm * 32 + ii * 16 + l15;
+        const int col = wn * 64 + j * 16 + 4 * l4;
+        const f32x4 a = acc[pass * 2 + ii][j];
+        *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+    __syncthreads();
+    drain_tile<128, B4N, 1024>(smem, PITCH, e, cp, M, N, n0, tid,
+                               [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+  }
+}
+
 // dynamic LDS: the staging ring, or the padded fp32 epilogue tile if larger
 static constexpr int LDS128 = (BM * (BN * 4 + 16)) > 2 * STAGE_BYTES ? (BM * (BN * 4 + 16)) : 2 * STAGE_BYTES;
 static constexpr int LDS5 = (128 * (B5N * 4 + 16)) > B5_SLOTS * B5_STAGE ? (128 * (B5N * 4 + 16)) : B5_SLOTS * B5_STAGE;
 static constexpr int LDS7 = (128 * (B4N * 4 + 16)) > 2 * B7_STAGE ? (128 * (B4N * 4 + 16)) : 2 * B7_STAGE;
+static constexpr int LDS9 = (128 * (B4N * 4 + 16)) > B9_SLOTS * B9_STAGE ? (128 * (B4N * 4 + 16)) : B9_SLOTS * B9_STAGE;
 static constexpr int LDS256 = (128 * (B4N * 4 + 16)) > B4_SLOTS * B4_STAGE ? (128 * (B4N * 4 + 16)) : B4_SLOTS * B4_STAGE;
 
 extern "C" int dod_debug_gemm_stamps(void* dev_buf) {
@@ -718,6 +836,9 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256x64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS7);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_m16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256_w16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS9);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256_w16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS9);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256_w16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS9);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
@@ -732,7 +853,18 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   const bool m16 = force ? (force[0] == '8') : (M >= 1024 && N >= 128);
   const bool mid = force ? (force[0] == '5') : false;
   const bool big = force ? (force[0] == '2') : false;
-  if (m16) {
+  // 16-wave 256x256 for long K (fc2: 581 vs 622 us at M = 87680): its 130 us fixed cost only pays off there
+  const bool w16 = force ? (force[0] == '9') : (M >= 4096 && N >= 512 && K >= 2048);
+  if (w16) {
+    static const char* gme9 = getenv("DINODET_GEMM_GM");
+    const int gm = gme9 ? atoi(gme9) : 4;
+    const int tiles = ((M + B4M - 1) / B4M) * ((N + B4N - 1) / B4N);
+    static const char* ab9 = getenv("DINODET_GEMM_ABL");
+    const int abl9 = ab9 ? atoi(ab9) : 0;
+    if (abl9 == 1) hipLaunchKernelGGL(gemm_bf16_256x256_w16_kernel<1>, dim3(tiles), dim3(1024), LDS9, s, A, lda, W, ldw, M, N, K, e, gm);
+    else if (abl9 == 3) hipLaunchKernelGGL(gemm_bf16_256x256_w16_kernel<3>, dim3(tiles), dim3(1024), LDS9, s, A, lda, W, ldw, M, N, K, e, gm);
+    else hipLaunchKernelGGL(gemm_bf16_256x256_w16_kernel<0>, dim3(tiles), dim3(1024), LDS9, s, A, lda, W, ldw, M, N, K, e, gm);
+  } else if (m16) {
     // grouped-order depth (m-tiles per group inside an XCD's run), measured: 8 for N = 3072, 4 for 2304, 2 for 768
     static const char* gme = getenv("DINODET_GEMM_GM");
     const int gm = gme ? atoi(gme) : (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2));
