@@ -141,7 +141,8 @@ def main():
                     model.forward_packed(x)
                 torch.cuda.current_stream().wait_stream(s)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # thread_local: an RCCL watchdog thread polling events must not invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     static_det = model.forward_packed(x)
                 if world > 1:
                     def run():
