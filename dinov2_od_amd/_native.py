@@ -54,6 +54,7 @@ SYMBOLS = {
     "dod_op_pos_resize": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "dod_op_im2col": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "dod_debug_gemm_stamps": (_I, [_P]),
+    "dod_debug_attn_stamps": (_I, [_P]),
     "dod_version": (C.c_char_p, []),
     "dod_device_count": (_I, []),
 }

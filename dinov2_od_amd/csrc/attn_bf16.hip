@@ -78,6 +78,8 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     const float lsum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])) +
                        (((ps[8] + ps[9]) + (ps[10] + ps[11])) + ((ps[12] + ps[13]) + (ps[14] + ps[15])));
     l_run[q] = fmaf(l_run[q], alpha, lsum);   // per-half partial; the halves are combined once at the end
+    // (a thresholded "lazy" rescale behind a wave-uniform branch was measured 4 % SLOWER: the branch splits the
+    //  scheduling region; the unconditional 16 packed multiplies are cheaper)
     o[q][0] *= alpha;
     o[q][1] *= alpha;
     // P^T fragments: accumulator registers 8u..8u+7 of key block kb are the B operand of k-step 2kb+u
@@ -134,6 +136,9 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     }
   }
 }
+
+// tuning only (tools/attn_timeline.py): per workgroup {cycles total, cycles waiting for DMA + barrier, tiles, blockIdx}
+__device__ unsigned long long* g_attn_stamps = nullptr;
 
 template <int AT_NQ>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
@@ -219,11 +224,17 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
   AT_STAGE(0, 0)
   if (nkt > 1) AT_STAGE(1, 1)
   int slot = 0;
+  unsigned long long* stamps = g_attn_stamps;
+  unsigned long long t_begin = 0, t_wait = 0;
+  if (stamps) t_begin = __builtin_amdgcn_s_memtime();
   for (int kt = 0; kt < nkt; ++kt) {
+    unsigned long long tw0 = 0;
+    if (stamps) tw0 = __builtin_amdgcn_s_memtime();
     if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // tile kt landed, tile kt+1 may fly
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (stamps) t_wait += __builtin_amdgcn_s_memtime() - tw0;
     if (kt + 2 < nkt) {
       const int ns = slot >= 1 ? slot - 1 : 2;      // (slot + 2) % 3: the slot tile kt-1 just vacated
       AT_STAGE(ns, kt + 2)
@@ -237,6 +248,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
     slot = slot == 2 ? 0 : slot + 1;
   }
 
+  if (stamps && tid == 0) {
+    unsigned long long* o_ = stamps + (size_t)blockIdx.x * 4;
+    o_[0] = __builtin_amdgcn_s_memtime() - t_begin; o_[1] = t_wait; o_[2] = nkt; o_[3] = active ? 1 : 0;
+  }
 #pragma unroll
   for (int qi = 0; qi < AT_NQ; ++qi) {
     const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
@@ -255,6 +270,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
         }
     }
   }
+}
+
+extern "C" int dod_debug_attn_stamps(void* dev_buf) {
+  unsigned long long* p = (unsigned long long*)dev_buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 4;
 }
 
 int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s) {

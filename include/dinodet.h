@@ -151,6 +151,8 @@ int dod_op_im2col(const float* img, int B, int H, int W, int patch, int Kp, void
  * {realtime at start, after the K loop, at exit, blockIdx} (100 MHz s_memrealtime); NULL switches it off.
  * Used by tools/gemm_timeline.py. */
 int dod_debug_gemm_stamps(void* dev_buf);
+/* same for the bf16 attention kernel: {shader cycles in the tile loop, cycles waiting for DMA + barrier, tiles, active} */
+int dod_debug_attn_stamps(void* dev_buf);
 
 const char* dod_version(void);
 /* Devices visible to the HIP runtime libdinodet.so is bound to (<= 0: none / error).  The host uses it to

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Per-workgroup cycle split of the bf16 attention kernel: tile loop total vs time waiting for K/V DMA + barrier."""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+from dinov2_od_amd import _native as nat
+L = nat.lib(); dev = torch.device("cuda:0")
+B, N, D = int(os.environ.get("PROF_B", "64")), 1370, 768
+g = torch.Generator().manual_seed(0)
+qkv = (torch.randn(B, N, 3 * D, generator=g) * 0.5).to(dev).to(torch.bfloat16); ctx = torch.empty(B, N, D, device=dev, dtype=torch.bfloat16)
+run = lambda: L.dod_op_attention_bf16(nat.ptr(qkv), nat.ptr(ctx), B, N, D // 64, 0.125, nat.stream_ptr())
+for _ in range(3): run()
+torch.cuda.synchronize()
+nblk = ((B * 12 + 7) // 8 * 8) * ((N + 255) // 256)
+buf = torch.zeros(nblk * 4 + 64, dtype=torch.int64, device=dev)
+L.dod_debug_attn_stamps(C.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); L.dod_debug_attn_stamps(C.c_void_p(0))
+t = buf.cpu().numpy()[: nblk * 4].reshape(nblk, 4).astype(np.float64)
+t = t[t[:, 2] > 0]
+act = t[t[:, 3] > 0]
+print(f"workgroups {len(t)}; tile loop cycles/tile median {np.median(act[:,0]/act[:,2]):.0f}; waiting (DMA+barrier) {100*np.median(act[:,1]/act[:,0]):.1f}% of it "
+      f"(p10 {100*np.percentile(act[:,1]/act[:,0],10):.1f}% p90 {100*np.percentile(act[:,1]/act[:,0],90):.1f}%)")
