@@ -37,12 +37,13 @@ def sync():
     torch.cuda.synchronize()
 
 
-def op_linear(A, W, bias=None, scale=None, resid=None, act="none", out_dtype=torch.float32):
-    """through dod_op_linear; A [M,K], W [N,K] both fp32 or both bf16 CUDA tensors"""
+def op_linear(A, W, bias=None, scale=None, resid=None, act="none", out_dtype=torch.float32, out=None):
+    """through dod_op_linear; A [M,K], W [N,K] both fp32 or both bf16 CUDA tensors (out: write there, e.g. in place)"""
     L = nat.lib()
     M, K = A.shape
     N = W.shape[0]
-    out = torch.empty(M, N, dtype=out_dtype, device=A.device)
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=A.device)
     in_dt = nat.DOD_BF16 if A.dtype == torch.bfloat16 else nat.DOD_F32
     out_dt = nat.DOD_BF16 if out_dtype == torch.bfloat16 else nat.DOD_F32
     rc = L.dod_op_linear(in_dt, nat.ptr(A), A.stride(0), nat.ptr(W), W.stride(0), M, N, K, nat.ptr(bias), nat.ptr(scale),

@@ -79,6 +79,25 @@ def test_linear_bf16_all_epilogues(G, M, N, K):
     r = G.to_gpu(resid)
     out = G.op_linear(Ad, Wd, G.to_gpu(bias), G.to_gpu(scale), r, "none")
     assert rel_err(out.cpu().numpy(), want.numpy()) < 3e-6
+    # x += A W^T + b without LayerScale (decoder residuals)
+    want = ref + torch.from_numpy(bias).double() + torch.from_numpy(resid).double()
+    out = G.op_linear(Ad, Wd, G.to_gpu(bias), None, r, "none")
+    assert rel_err(out.cpu().numpy(), want.numpy()) < 3e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(1370, 768, 768), (2740 + 37, 768, 768), (4110 + 5, 768, 3072), (4500, 1024, 2048), (1500, 384, 384)])
+def test_linear_bf16_residual_in_place(G, M, N, K):
+    """out-proj / fc2 as the forward issues them: the fp32 residual stream updated in place (256x128 kernel for K < 2048,
+    16-wave 256x256 kernel above; ragged last m-tile)."""
+    A = torch.from_numpy(_n("ri.A", (M, K))).to(torch.bfloat16)
+    W = torch.from_numpy(_n("ri.W", (N, K), 0.05)).to(torch.bfloat16)
+    bias, resid = _n("ri.b", (N,)), _n("ri.r", (M, N), 3.0)
+    want = A.double() @ W.double().t() + torch.from_numpy(bias).double() + torch.from_numpy(resid).double()
+    x = G.to_gpu(resid)
+    out = G.op_linear(A.to(G.dev()), W.to(G.dev()), G.to_gpu(bias), None, x, "none", out=x)
+    assert out.data_ptr() == x.data_ptr()
+    assert rel_err(x.cpu().numpy(), want.numpy()) < 3e-6
 
 
 def test_linear_rejects_bad_shapes(G):

@@ -29,11 +29,13 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--res", type=int, default=518)
     ap.add_argument("--hidden", type=int, default=768)
+    ap.add_argument("--layerscale", action="store_true", help="LayerScale in the residual epilogues (fp32-mode form; the bf16 path folds it into W)")
+    ap.add_argument("--rows", type=int, default=0, help="override M of the GEMMs (tail / wave-quantisation studies)")
     a = ap.parse_args()
     L = nat.lib()
     dev = torch.device("cuda:0")
     N = (a.res // 14) ** 2 + 1
-    M, D = a.batch * N, a.hidden
+    M, D = a.rows or a.batch * N, a.hidden
     heads = D // 64
     g = torch.Generator(device="cpu").manual_seed(0)
     rnd = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dev)
@@ -49,12 +51,14 @@ def main():
 
         def run():
             if epi == "resid":
-                rc = L.dod_op_linear(1, nat.ptr(A), k, nat.ptr(W), k, m, n, k, nat.ptr(bias), nat.ptr(scale), nat.ptr(x), n, nat.ptr(x), 0, n, 0, nat.stream_ptr())
+                rc = L.dod_op_linear(1, nat.ptr(A), k, nat.ptr(W), k, m, n, k, nat.ptr(bias), nat.ptr(scale) if a.layerscale else None, nat.ptr(x), n, nat.ptr(x), 0, n, 0, nat.stream_ptr())
             else:
                 rc = L.dod_op_linear(1, nat.ptr(A), k, nat.ptr(W), k, m, n, k, nat.ptr(bias), None, None, 0, nat.ptr(out), 1, n, 2 if epi == "gelu" else 0, nat.stream_ptr())
             assert rc == 0
         t = timeit(run)
         print(f"gemm_bf16 {name:5s} M={m} N={n} K={k}: {t*1e6:8.1f} us  {2.0*m*n*k/t/1e12:7.1f} TFLOP/s")
+    if a.rows:
+        return
     qkv = rnd(a.batch, N, 3 * D).to(torch.bfloat16)
     ctx = torch.empty(a.batch, N, D, device=dev, dtype=torch.bfloat16)
     t = timeit(lambda: L.dod_op_attention_bf16(nat.ptr(qkv), nat.ptr(ctx), a.batch, N, heads, 0.125, nat.stream_ptr()))

@@ -16,7 +16,7 @@ for N, K, obf in ((2304, 768, True), (768, 768, False), (768, 3072, False)):
     buf = torch.zeros(tiles * 4, dtype=torch.int64, device=dev)
     def run():
         if obf: L.dod_op_linear(1, nat.ptr(A), K, nat.ptr(W), K, M, N, K, nat.ptr(bias), None, None, 0, nat.ptr(out), 1, N, 0, nat.stream_ptr())
-        else: L.dod_op_linear(1, nat.ptr(A), K, nat.ptr(W), K, M, N, K, nat.ptr(bias), nat.ptr(scale), nat.ptr(x), N, nat.ptr(x), 0, N, 0, nat.stream_ptr())
+        else: L.dod_op_linear(1, nat.ptr(A), K, nat.ptr(W), K, M, N, K, nat.ptr(bias), nat.ptr(scale) if os.environ.get('TL_LAYERSCALE') else None, nat.ptr(x), N, nat.ptr(x), 0, N, 0, nat.stream_ptr())
     for _ in range(3): run()
     torch.cuda.synchronize()
     L.dod_debug_gemm_stamps(C.c_void_p(buf.data_ptr()))
