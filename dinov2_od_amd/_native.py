@@ -55,6 +55,7 @@ SYMBOLS = {
     "dod_op_im2col": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "dod_debug_gemm_stamps": (_I, [_P]),
     "dod_debug_attn_stamps": (_I, [_P]),
+    "dod_debug_mfma_peak": (_I, [_I, _I, _I, _P, _P]),
     "dod_version": (C.c_char_p, []),
     "dod_device_count": (_I, []),
 }

@@ -14,6 +14,7 @@
 // N = 1370 is not a multiple of 64: the last tile's keys >= N get -inf before the row max; loads of
 // rows >= N are clamped to row N-1 (finite values times p = 0).
 #include "dod_common.h"
+#include <cstdlib>
 
 #define AT_WAVES 4
 // AT_NQ (32-row query blocks per wave) is a template parameter of the kernel: 2 for large launches, 1 for small ones
@@ -64,15 +65,27 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[q][0][r]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[q][1][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    {   // other half's max by v_permlane32_swap (VALU; __shfl_xor goes through the LDS crossbar and an lgkmcnt wait)
+      const unsigned mb = __float_as_uint(mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
     const float m_new = fmaxf(m_run[q], mx * c);            // scaled (exp2-domain) running max
     const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_new);
     m_run[q] = m_new;
     const float nm = -m_new;
+    {
+      typedef float f32x2_ __attribute__((ext_vector_type(2)));
+      const f32x2_ c2 = {c, c}, nm2 = {nm, nm};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[q][0][r] = __builtin_amdgcn_exp2f(fmaf(s[q][0][r], c, nm));
-      s[q][1][r] = __builtin_amdgcn_exp2f(fmaf(s[q][1][r], c, nm));
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {   // v_pk_fma_f32: two scores per VALU issue slot
+          f32x2_ v = {s[q][kb][r], s[q][kb][r + 1]};
+          v = __builtin_elementwise_fma(v, c2, nm2);
+          s[q][kb][r] = __builtin_amdgcn_exp2f(v.x);
+          s[q][kb][r + 1] = __builtin_amdgcn_exp2f(v.y);
+        }
     }
     const f32x16 ps = s[q][0] + s[q][1];
     const float lsum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])) +
@@ -137,7 +150,8 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
   }
 }
 
-// tuning only (tools/attn_timeline.py): per workgroup {cycles total, cycles waiting for DMA + barrier, tiles, blockIdx}
+// tuning only (tools/attn_timeline.py): per workgroup {tile-loop cycles, cycles waiting for DMA + barrier, tiles, active,
+// s_memrealtime (100 MHz) at kernel entry, at the end of the tile loop}; the exit time is the next workgroup's entry
 __device__ unsigned long long* g_attn_stamps = nullptr;
 
 template <int AT_NQ>
@@ -147,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int D = heads * 64, ld = 3 * D;
+  const unsigned long long rt_entry = g_attn_stamps ? __builtin_amdgcn_s_memrealtime() : 0;
   // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs, so the q-blocks of one (image, head)
   // -- which all stream the same 350 KB of K/V -- are placed on ONE XCD (pair p -> XCD p % 8) and run back to back
   // there; with the plain (q-block, head, image) grid each XCD saw ~70 different pairs at once (24 MB of K/V
@@ -249,8 +264,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
   }
 
   if (stamps && tid == 0) {
-    unsigned long long* o_ = stamps + (size_t)blockIdx.x * 4;
+    unsigned long long* o_ = stamps + (size_t)blockIdx.x * 6;
     o_[0] = __builtin_amdgcn_s_memtime() - t_begin; o_[1] = t_wait; o_[2] = nkt; o_[3] = active ? 1 : 0;
+    o_[4] = rt_entry; o_[5] = __builtin_amdgcn_s_memrealtime();
   }
 #pragma unroll
   for (int qi = 0; qi < AT_NQ; ++qi) {
@@ -283,7 +299,8 @@ int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, fl
   const float c = scale * 1.44269504088896340736f;
   // 64 query rows per wave once the grid still fills the chip several times over (measured: +5 % at B*heads = 768,
   // -12 % at 96), else 32
-  if ((long)npairs * ((N + 255) / 256) >= 4 * 256) {
+  static const char* nqe = getenv("DINODET_ATTN_NQ");   // tuning override
+  if (nqe ? nqe[0] == '2' : (long)npairs * ((N + 255) / 256) >= 4 * 256) {
     const int nqb = (N + AT_WAVES * 64 - 1) / (AT_WAVES * 64);
     hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c);
   } else {

@@ -890,3 +890,50 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
+
+// ---- tuning only (tools/mfma_peak.py): register-only MFMA loop, no memory traffic -----------------------------
+// Each wave runs `iters` rounds of 8 independent v_mfma_f32_16x16x32_bf16 (or 4 x 32x32x16) accumulator chains.
+// out[block*4 + {0,1,2}] = {s_memtime cycles of wave 0, s_memrealtime ticks (100 MHz) of wave 0, checksum}.
+template <int SHAPE>
+__global__ __launch_bounds__(256, 2) void mfma_peak_kernel(int iters, unsigned long long* out) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (bf16_t)(0x3c00 + threadIdx.x + i); b[i] = (bf16_t)(0x3c10 + threadIdx.x * 3 + i); }
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float chk = 0.f;
+  if (SHAPE == 16) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) chk += acc[i][0];
+  } else {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) chk += acc[i][0];
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    out[(size_t)blockIdx.x * 4 + 0] = c1 - c0;
+    out[(size_t)blockIdx.x * 4 + 1] = r1 - r0;
+    out[(size_t)blockIdx.x * 4 + 2] = (unsigned long long)__float_as_uint(chk);
+  }
+}
+extern "C" int dod_debug_mfma_peak(int shape, int iters, int blocks, void* dev_out, void* stream) {
+  if (!dev_out || iters <= 0 || blocks <= 0 || (shape != 16 && shape != 32)) return 1;
+  if (shape == 16) hipLaunchKernelGGL(mfma_peak_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)dev_out);
+  else hipLaunchKernelGGL(mfma_peak_kernel<32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)dev_out);
+  return hipGetLastError() == hipSuccess ? 0 : 4;
+}

@@ -12,10 +12,19 @@ run = lambda: L.dod_op_attention_bf16(nat.ptr(qkv), nat.ptr(ctx), B, N, D // 64,
 for _ in range(3): run()
 torch.cuda.synchronize()
 nblk = ((B * 12 + 7) // 8 * 8) * ((N + 255) // 256)
-buf = torch.zeros(nblk * 4 + 64, dtype=torch.int64, device=dev)
+buf = torch.zeros(nblk * 6 + 64, dtype=torch.int64, device=dev)
 L.dod_debug_attn_stamps(C.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); L.dod_debug_attn_stamps(C.c_void_p(0))
-t = buf.cpu().numpy()[: nblk * 4].reshape(nblk, 4).astype(np.float64)
+t = buf.cpu().numpy()[: nblk * 6].reshape(nblk, 6).astype(np.float64)
 t = t[t[:, 2] > 0]
 act = t[t[:, 3] > 0]
 print(f"workgroups {len(t)}; tile loop cycles/tile median {np.median(act[:,0]/act[:,2]):.0f}; waiting (DMA+barrier) {100*np.median(act[:,1]/act[:,0]):.1f}% of it "
       f"(p10 {100*np.percentile(act[:,1]/act[:,0],10):.1f}% p90 {100*np.percentile(act[:,1]/act[:,0],90):.1f}%)")
+t0 = act[:, 4].min()
+entry, loop_end = (act[:, 4] - t0) / 100.0, (act[:, 5] - t0) / 100.0
+print(f"kernel span (first entry -> last loop end) {loop_end.max():.1f} us; per WG entry -> loop end median {np.median(loop_end - entry):.2f} us "
+      f"(p10 {np.percentile(loop_end - entry, 10):.2f}, p90 {np.percentile(loop_end - entry, 90):.2f}); tiles/WG {act[0,2]:.0f}")
+slots = 512
+print(f"sum of WG (entry -> loop end) / {slots} slots = {np.sum(loop_end - entry) / slots:.1f} us")
+order = np.argsort(entry)
+e = entry[order]
+print("entries per 50-us window:", np.histogram(e, bins=np.arange(0, loop_end.max() + 50, 50))[0])

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Sustained bf16 MFMA rate and clock of this MI355X under a register-only MFMA loop (no memory traffic):
+context for the roofline fractions in DESIGN.md (the 2.5 PFLOP/s denominator assumes the 2.4 GHz peak clock)."""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dinov2_od_amd import _native as nat
+
+L = nat.lib()
+dev = torch.device("cuda:0")
+for shape, chains, flop in ((16, 8, 2 * 16 * 16 * 32), (32, 4, 2 * 32 * 32 * 16)):
+    for wg_per_cu in (1, 2, 4):
+        blocks, iters = 256 * wg_per_cu, 20000
+        out = torch.zeros(blocks * 4, dtype=torch.int64, device=dev)
+        for _ in range(2):
+            nat.check(L.dod_debug_mfma_peak(shape, iters, blocks, nat.ptr(out), nat.stream_ptr()))
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        nat.check(L.dod_debug_mfma_peak(shape, iters, blocks, nat.ptr(out), nat.stream_ptr()))
+        b.record()
+        torch.cuda.synchronize()
+        t = a.elapsed_time(b) * 1e-3
+        o = out.view(blocks, 4).cpu().double()
+        cyc, ticks = o[:, 0].median().item(), o[:, 1].median().item()
+        total = float(blocks) * 4 * iters * chains * flop
+        print(f"mfma {shape}: {wg_per_cu} WG/CU ({wg_per_cu} waves/SIMD): {total / t / 1e12:7.1f} TFLOP/s wall; "
+              f"s_memtime {cyc / (ticks / 100e6) / 1e9:5.2f} G counts/s; {cyc / (iters * chains):6.2f} counts per MFMA per wave")
