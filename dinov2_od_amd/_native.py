@@ -29,6 +29,12 @@ class DodConfig(C.Structure):
 
 _P, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
+
+class DodDetection(C.Structure):
+    """struct dod_detection (include/dinodet.h): one COCO-style record of evaluate_coco, utils.py:225-233"""
+    _fields_ = [("image_id", C.c_int64), ("category_id", C.c_int32), ("query", C.c_int32), ("bbox", C.c_float * 4),
+                ("score", C.c_float), ("reserved", C.c_int32)]
+
 # name -> (restype, argtypes): every symbol include/dinodet.h declares
 SYMBOLS = {
     "dod_create": (_I, [C.POINTER(DodConfig), C.POINTER(_P)]),
@@ -53,6 +59,8 @@ SYMBOLS = {
     "dod_op_deform_sample": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dod_op_pos_resize": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "dod_op_im2col": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "dod_postprocess_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "dod_postprocess": (_I, [_P, _I, _I, _I, _P, _F, _P, C.c_int64, _P, _P, _SZ, _P]),
     "dod_debug_gemm_stamps": (_I, [_P]),
     "dod_debug_attn_stamps": (_I, [_P]),
     "dod_debug_mfma_peak": (_I, [_I, _I, _I, _P, _P]),

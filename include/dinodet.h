@@ -147,6 +147,27 @@ int dod_op_pos_resize(const float* pos_in, int G, int gh, int gw, int D, float* 
 /* img [B,3,H,W] -> cols [B*(H/p)*(W/p), Kp] of out_dtype */
 int dod_op_im2col(const float* img, int B, int H, int W, int patch, int Kp, void* out, int out_dtype, void* stream);
 
+/* ---- detection post-processing on device ---------------------------------------
+ * Replaces the per-image / per-class / per-query loop of evaluate_coco, dino_detector/utils.py:195-233:
+ * sigmoid scores (:198), background class 0 skipped (:211-212), score > threshold (0.05 at :215), cxcywh -> xyxy
+ * (:86-87) -> COCO [x, y, w, h] (:225), one record per kept (image, class, query) in the reference's order
+ * (image-major, then class 1..C-1, then query).  `query` is extra (the reference drops it). */
+typedef struct dod_detection {
+  int64_t image_id;       /* image_ids[b], or b when image_ids is NULL (target.get('image_id', i), utils.py:203) */
+  int32_t category_id;    /* class index c, 1..C-1 */
+  int32_t query;          /* query index q */
+  float bbox[4];          /* x1, y1, x2 - x1, y2 - y1 (normalised, as the reference emits them) */
+  float score;            /* sigmoid(logit) */
+  int32_t reserved;
+} dod_detection;          /* 40 bytes */
+size_t dod_postprocess_workspace_bytes(int B, int Q, int C);
+/* det: packed detections [B, Q, C+4] fp32 (the output of dod_forward), image_ids: device int64 [B] or NULL.
+ * Writes min(total, max_out) records to `out` (device) and the TOTAL number of kept detections to *count (device
+ * int64; > max_out means truncated).  Enqueued on `stream`; no host synchronisation. */
+int dod_postprocess(const float* det, int B, int Q, int C, const int64_t* image_ids, float threshold,
+                    dod_detection* out, int64_t max_out, int64_t* count, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
 /* Tuning aid: when dev_buf is non-NULL the large bf16 GEMM kernel stores 4 x uint64 per workgroup
  * {realtime at start, after the K loop, at exit, blockIdx} (100 MHz s_memrealtime); NULL switches it off.
  * Used by tools/gemm_timeline.py. */

@@ -160,6 +160,49 @@ def g1_decoder_only():
     _save("g1_decoder_only", **out)
 
 
+def postprocess_inputs(B=5, Q=25, C=11, seed=11):
+    """packed detections [B,Q,C+4]: logits ~ N(-3.2, 1.6) (about a third above the 0.05 score threshold), boxes
+    uniform; logits whose score is within 1e-4 of the threshold are moved away (sigmoid implementations differ by an ulp)."""
+    logits = (synth.normal(seed, "pp.logits", (B, Q, C), 1.6) - 3.2).astype(np.float32)
+    s = 1.0 / (1.0 + np.exp(-logits.astype(np.float64)))
+    logits[np.abs(s - 0.05) < 1e-4] -= 0.05
+    boxes = synth.uniform01(seed, "pp.boxes", (B, Q, 4)).astype(np.float32)
+    return np.concatenate([logits, boxes], axis=-1)
+
+
+def g5_postprocess():
+    """G5: the reference's evaluate_coco (utils.py:167-240) on fixed model outputs: two batches (3 + 2 images), one target
+    without an image_id (falls back to the index in the batch, utils.py:203)."""
+    from dino_detector.utils import evaluate_coco
+    det = postprocess_inputs()
+    C = det.shape[-1] - 4
+    batches = [(0, 3), (3, 5)]
+    ids = [[42, None, 100013], [7, 8]]
+
+    class Fixed(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.i = 0
+
+        def forward(self, images):
+            lo, hi = batches[self.i]
+            self.i += 1
+            d = torch.from_numpy(det[lo:hi])
+            return {"pred_logits": d[..., :C].contiguous(), "pred_boxes": d[..., C:].contiguous()}
+
+    loader = [(torch.zeros(hi - lo, 3, 8, 8), [({"image_id": i} if i is not None else {}) for i in ids_b])
+              for (lo, hi), ids_b in zip(batches, ids)]
+    res = evaluate_coco(Fixed(), loader, torch.device("cpu"), None)
+    _save("g5_postprocess", det=det,
+          batch_bounds=np.array(batches, dtype=np.int64),
+          image_ids=np.array([[-1 if i is None else i for i in (b + [-1] * 3)[:3]] for b in ids], dtype=np.int64),
+          r_image_id=np.array([r["image_id"] for r in res], dtype=np.int64),
+          r_category_id=np.array([r["category_id"] for r in res], dtype=np.int32),
+          r_bbox=np.array([r["bbox"] for r in res], dtype=np.float64),
+          r_score=np.array([r["score"] for r in res], dtype=np.float64))
+    print(f"g5: {len(res)} records")
+
+
 def _e2e(name, model_name, R, B, kwargs, probes=True):
     from dinov2_od_amd.config import variant_of, BACKBONE_VARIANTS
     hid = kwargs.get("hidden_dim", 768)
@@ -200,7 +243,7 @@ def g3_vitb():
 
 
 CASES = dict(g0=lambda: g0_micro_backbone(False), g4=lambda: g0_micro_backbone(True),
-             g1=g1_decoder_only, g2=g2_cfg1, g3=g3_vitb)
+             g1=g1_decoder_only, g2=g2_cfg1, g3=g3_vitb, g5=g5_postprocess)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -87,3 +87,23 @@ def test_bicubic_restatement_matches_torch():
     want = torch.nn.functional.interpolate(src[None], size=(16, 16), mode="bicubic", align_corners=False)[0]
     got = orc.bicubic_resize_ref(src, 16, 16)
     assert rel_err(got.numpy(), want.numpy()) < 1e-6
+
+
+def test_postprocess_oracle_matches_reference_evaluate_coco():
+    """G5: the numpy restatement of utils.py:195-233 against the reference's evaluate_coco output"""
+    from oracle import postprocess_oracle as ppo
+    g = cases.golden("g5_postprocess")
+    det = g["det"]
+    C = det.shape[-1] - 4
+    got = {k: [] for k in ("image_id", "category_id", "bbox", "score")}
+    for (lo, hi), ids in zip(g["batch_bounds"], g["image_ids"]):
+        ids = [None if v < 0 else int(v) for v in ids[: hi - lo]]
+        r = ppo.postprocess(det[lo:hi], C, ids, 0.05)
+        for k in got:
+            got[k].append(r[k])
+    got = {k: np.concatenate(v) for k, v in got.items()}
+    assert len(got["image_id"]) == len(g["r_image_id"]) > 100
+    assert np.array_equal(got["image_id"], g["r_image_id"])
+    assert np.array_equal(got["category_id"], g["r_category_id"])
+    assert np.array_equal(got["bbox"].astype(np.float64), g["r_bbox"])            # bit-exact fp32 box arithmetic
+    assert np.max(np.abs(got["score"].astype(np.float64) - g["r_score"])) < 2e-7  # sigmoid: <= 1-2 ulp of fp32
