@@ -168,6 +168,17 @@ int dod_postprocess(const float* det, int B, int Q, int C, const int64_t* image_
                     dod_detection* out, int64_t max_out, int64_t* count, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* ---- Hungarian-matcher cost matrices on device -------------------------------------
+ * Replaces the per-image cost computation of HungarianMatcher.forward, dino_detector/matching.py:79-98 (focal class
+ * cost :80-86, L1 box cost :89, GIoU cost :92-95 with utils.py:124-164, weighted sum :98) for the whole batch.
+ * Targets are concatenated: labels int64 [G], gt_boxes fp32 [G,4] (cx,cy,w,h), gt_offsets int32 [B+1] (device).
+ * cost (device fp32, G*Q floats): image b's matrix [Q, n_b] row-major at cost + gt_offsets[b]*Q -- exactly the C_valid
+ * the reference hands to scipy (:102-105).  rows_from: -1 = image b's own predictions; k >= 0 = the predictions of
+ * image k for EVERY image (the reference slices C[:num_queries] of a matrix built over all B*Q rows, i.e. k = 0). */
+int dod_match_cost(const float* det, int B, int Q, int C, const int64_t* labels, const float* gt_boxes,
+                   const int32_t* gt_offsets, int G, float w_class, float w_bbox, float w_giou, float alpha, float gamma,
+                   int rows_from, float* cost, void* stream);
+
 /* Tuning aid: when dev_buf is non-NULL the large bf16 GEMM kernel stores 4 x uint64 per workgroup
  * {realtime at start, after the K loop, at exit, blockIdx} (100 MHz s_memrealtime); NULL switches it off.
  * Used by tools/gemm_timeline.py. */

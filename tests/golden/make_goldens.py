@@ -203,6 +203,60 @@ def g5_postprocess():
     print(f"g5: {len(res)} records")
 
 
+def matcher_inputs(B=4, Q=25, C=11, counts=(4, 0, 7, 30), seed=13):
+    """packed detections + concatenated targets (labels, cxcywh boxes, offsets): image 1 has no boxes, image 3 has more
+    targets than queries' worth of easy matches (30 > 25: a rectangular assignment)"""
+    logits = synth.normal(seed, "mt.logits", (B, Q, C), 2.0).astype(np.float32)
+    cxcy = 0.15 + 0.7 * synth.uniform01(seed, "mt.cxcy", (B, Q, 2))
+    wh = 0.05 + 0.4 * synth.uniform01(seed, "mt.wh", (B, Q, 2))
+    det = np.concatenate([logits, cxcy, wh], axis=-1).astype(np.float32)
+    G = int(sum(counts))
+    labels = (synth.uniform01(seed, "mt.labels", (G,)) * C).astype(np.int64).clip(0, C - 1)
+    gcxcy = 0.15 + 0.7 * synth.uniform01(seed, "mt.gcxcy", (G, 2))
+    gwh = 0.05 + 0.4 * synth.uniform01(seed, "mt.gwh", (G, 2))
+    gt = np.concatenate([gcxcy, gwh], axis=-1).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return det, labels, gt, offs
+
+
+def g6_matcher():
+    """G6: the reference's HungarianMatcher (matching.py:43-121) on fixed outputs/targets.  The cost matrices it hands to
+    scipy are captured by wrapping `linear_sum_assignment` in the reference module's namespace (nothing is restated)."""
+    import dino_detector.matching as rm
+    det, labels, gt, offs = matcher_inputs()
+    B, Q = det.shape[:2]
+    C = det.shape[-1] - 4
+    captured = []
+    real = rm.linear_sum_assignment
+
+    def spy(cm):
+        captured.append(np.array(cm, dtype=np.float32, copy=True))
+        return real(cm)
+
+    rm.linear_sum_assignment = spy
+    try:
+        out = {}
+        for tag, kw in (("default", {}), ("g15", dict(cost_class=2.0, cost_bbox=1.0, cost_giou=3.0, focal_alpha=0.4, focal_gamma=1.5))):
+            captured.clear()
+            m = rm.HungarianMatcher(**kw)
+            d = torch.from_numpy(det)
+            outputs = {"pred_logits": d[..., :C].contiguous(), "pred_boxes": d[..., C:].contiguous()}
+            targets = [{"labels": torch.from_numpy(labels[offs[b]:offs[b + 1]]), "boxes": torch.from_numpy(gt[offs[b]:offs[b + 1]])}
+                       for b in range(B)]
+            idx = m(outputs, targets)
+            assert len(captured) == B
+            for b in range(B):
+                out[f"{tag}_cost{b}"] = captured[b]
+                out[f"{tag}_i{b}"] = idx[b][0].numpy()
+                out[f"{tag}_j{b}"] = idx[b][1].numpy()
+        # an empty target dict short-circuits (matching.py:73-75)
+        idx = rm.HungarianMatcher()(outputs, [{}] + targets[1:])
+        out["emptydict_n0"] = np.array([len(idx[0][0]), len(idx[0][1])])
+    finally:
+        rm.linear_sum_assignment = real
+    _save("g6_matcher", det=det, labels=labels, gt=gt, offs=offs, **out)
+
+
 def _e2e(name, model_name, R, B, kwargs, probes=True):
     from dinov2_od_amd.config import variant_of, BACKBONE_VARIANTS
     hid = kwargs.get("hidden_dim", 768)
@@ -243,7 +297,7 @@ def g3_vitb():
 
 
 CASES = dict(g0=lambda: g0_micro_backbone(False), g4=lambda: g0_micro_backbone(True),
-             g1=g1_decoder_only, g2=g2_cfg1, g3=g3_vitb, g5=g5_postprocess)
+             g1=g1_decoder_only, g2=g2_cfg1, g3=g3_vitb, g5=g5_postprocess, g6=g6_matcher)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -107,3 +107,21 @@ def test_postprocess_oracle_matches_reference_evaluate_coco():
     assert np.array_equal(got["category_id"], g["r_category_id"])
     assert np.array_equal(got["bbox"].astype(np.float64), g["r_bbox"])            # bit-exact fp32 box arithmetic
     assert np.max(np.abs(got["score"].astype(np.float64) - g["r_score"])) < 2e-7  # sigmoid: <= 1-2 ulp of fp32
+
+
+@pytest.mark.parametrize("tag,kw", [("default", {}), ("g15", dict(cost_class=2.0, cost_bbox=1.0, cost_giou=3.0, focal_alpha=0.4, focal_gamma=1.5))])
+def test_matching_oracle_matches_reference_matcher(tag, kw):
+    """G6: restated cost matrices vs the ones the reference's HungarianMatcher handed to scipy, and its assignment"""
+    from oracle import matching_oracle as mo
+    g = cases.golden("g6_matcher")
+    det, offs = g["det"], g["offs"]
+    C = det.shape[-1] - 4
+    costs = mo.cost_matrices(det, C, g["labels"], g["gt"], offs, rows_from=0, **kw)
+    idx = mo.assign(costs)
+    for b in range(det.shape[0]):
+        want = g[f"{tag}_cost{b}"]
+        assert costs[b].shape == want.shape
+        if want.size:
+            assert np.max(np.abs(costs[b] - want)) <= 1e-6 * max(1.0, np.abs(want).max())
+        assert np.array_equal(idx[b][0], g[f"{tag}_i{b}"]) and np.array_equal(idx[b][1], g[f"{tag}_j{b}"])
+    assert g["default_cost1"].shape == (det.shape[1], 0) and list(g["emptydict_n0"]) == [0, 0]
