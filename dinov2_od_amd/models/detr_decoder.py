@@ -99,6 +99,8 @@ class DETRDecoder(nn.Module, _EngineMixin):
 
     def forward(self, src):
         """src [batch, seq_len, hidden_dim] -> {"pred_logits": [B,Q,C], "pred_boxes": [B,Q,4]}"""
-        self._check_mode()
+        if self._use_autograd():
+            from . import _autograd
+            return _autograd.decoder_forward(self, src)
         det = self._get_engine().decoder_forward(src, self._engine_named())
         return split_detections(det, self._dc_cfg.num_classes)

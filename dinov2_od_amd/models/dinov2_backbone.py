@@ -124,11 +124,10 @@ class _EngineMixin:
             self.__dict__["_engine"] = eng
         return eng
 
-    def _check_mode(self):
-        if self.training and getattr(self, "_dropout_p", 0.0) > 0.0:
-            raise NotImplementedError(
-                "train-mode forward (dropout, deformable_attention.py:195-209) is not part of the native path "
-                "yet; call .eval() (SURVEY.md section 8f-1)")
+    def _use_autograd(self):
+        """train() mode -> the autograd composite (models/_autograd.py): the native kernels have no backward yet
+        (SURVEY.md section 8f-1).  eval() mode is always native."""
+        return self.training
 
     def set_precision(self, precision):
         self.precision = precision
@@ -171,4 +170,7 @@ class DINOv2Backbone(nn.Module, _EngineMixin):
 
     def forward(self, pixel_values):
         """-> features [batch, seq_len, hidden_dim] fp32, CLS token at index 0 (dinov2_backbone.py:58-67)"""
+        if self._use_autograd():
+            from . import _autograd
+            return _autograd.backbone_forward(self, pixel_values)
         return self._get_engine().backbone_forward(pixel_values, self._engine_named())

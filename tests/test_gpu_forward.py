@@ -191,6 +191,38 @@ def test_weights_resync_after_load_state_dict(G):
     assert rel_err(b[..., :91].cpu().numpy(), want["pred_logits"].numpy()) < TOL
 
 
+def test_train_step_then_native_eval(G):
+    """train.py:1079-1101 on the drop-in: train() forward is the autograd composite on the GPU, backward + SGD step move the
+    trainable subset, and the next eval() forward -- native kernels -- runs with the updated weights (automatic re-pack)."""
+    bb, dc = cases.cfg1(25)
+    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-small")
+    x = G.to_gpu(synth.make_pixels(2, 224, 224, seed=0))
+    before = m.forward_packed(x).clone()                      # native
+    m.train()
+    o = m(x)                                                  # composite, with dropout (config default 0.1)
+    assert o["pred_logits"].requires_grad and o["pred_logits"].is_cuda
+    loss = o["pred_logits"].square().mean() + (o["pred_boxes"] - 0.5).abs().mean()
+    loss.backward()
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.05)
+    opt.step()
+    m.eval()
+    after = m.forward_packed(x).clone()                       # native again, re-packed weights
+    assert not torch.allclose(before, after)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want = orc.detector_forward(sd, bb, dc, x.cpu().numpy())
+    assert rel_err(after[..., :91].cpu().numpy(), want["pred_logits"].numpy()) < TOL
+    assert rel_err(after[..., 91:].cpu().numpy(), want["pred_boxes"].numpy()) < TOL
+    # the composite in eval-equivalent form (no dropout) agrees with the native kernels on the same weights
+    m.train()
+    m._dropout_p = m.decoder._dropout_p = 0.0
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.MultiheadAttention, torch.nn.Dropout)):
+            mod.dropout = 0.0 if isinstance(mod, torch.nn.MultiheadAttention) else mod.p
+    with torch.no_grad():
+        comp = m(x)
+    assert rel_err(comp["pred_logits"].cpu().numpy(), after[..., :91].cpu().numpy()) < TOL
+
+
 def test_module_prefix_and_error_paths(G):
     from dinov2_od_amd import _native as nat
     bb, dc = cases.cfg1(25)
