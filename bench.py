@@ -34,10 +34,12 @@ WORKLOADS = {
     "vitb518": ("facebook/dinov2-base", 518, 100, 64, "ViT-B/14 518x518 bf16, 100 queries, batch 64 per GPU (BASELINE configs[2]'s batch of 64; it fits one GPU, so every GPU runs the whole configuration: weak scaling)"),
     "vitb224": ("facebook/dinov2-base", 224, 100, 32, "ViT-B/14 224x224 bf16, 100 queries, batch 32 per GPU (BASELINE configs[1])"),
     "vitl518": ("facebook/dinov2-large", 518, 300, 16, "ViT-L/14 518x518 bf16, 300 queries, batch 16 per GPU (BASELINE configs[3])"),
+    "vitg518": ("facebook/dinov2-giant", 518, 300, 32, "ViT-g/14 518x518, 300 queries, batch 32 per GPU (BASELINE configs[4]; --precision fp8 for its fp8 MFMA form)"),
     "vits224": ("facebook/dinov2-small", 224, 100, 2, "--lightweight ViT-S/14 224x224, batch 2 (BASELINE configs[0])"),
 }
 PEAK_BF16 = 2.5e15      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12
+PEAK_FP8 = 5.0e15       # dense fp8 MFMA (v_mfma_f32_32x32x64_f8f6f4), same guide
 
 
 def build(name, queries, precision, device):
@@ -111,7 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="vitb518", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     a = ap.parse_args()
@@ -204,8 +206,8 @@ def main():
     global_batch = B_local * world
     ips = global_batch * a.steps / dt
     fpi = flops_per_image(bb, dc, R, R)
-    dom = "gemm_bf16" if a.precision == "bf16" else "gemm_f32"
-    peak = PEAK_BF16 if a.precision == "bf16" else PEAK_F32
+    dom = {"bf16": "gemm_bf16", "fp32": "gemm_f32", "fp8": "gemm_fp8"}[a.precision]
+    peak = {"bf16": PEAK_BF16, "fp32": PEAK_F32, "fp8": PEAK_FP8}[a.precision]
     d = prof[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) if d["ms"] > 0 else 0.0
     traffic, traffic_src = None, None
@@ -214,7 +216,8 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (not measurable live)
         tdat = json.load(open(tj))
         traffic, traffic_src = tdat["gemm_bf16_avg_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
-    roof = {"bound": "mfma", "kernel": "gemm_bf16_256x128/256x256_kernel (all bf16 MFMA GEMM launches of the step)" if a.precision == "bf16" else "gemm_f32_kernel",
+    roof = {"bound": "mfma", "kernel": {"bf16": "gemm_bf16_256x128/256x256_kernel (all bf16 MFMA GEMM launches of the step)", "fp32": "gemm_f32_kernel",
+                                        "fp8": "gemm_fp8_256x128_kernel (the e4m3 MFMA GEMM launches: QKV, MLP-in, SwiGLU MLP-out)"}[a.precision],
             "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": d["launches"] // nprof, "avg_launch_us": 1e3 * d["ms"] / max(1, d["launches"]),

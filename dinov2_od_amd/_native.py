@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdinodet.so")
 
 DOD_F32, DOD_BF16 = 0, 1
-PREC = {"fp32": 0, "bf16": 1}
+PREC = {"fp32": 0, "bf16": 1, "fp8": 2}
 ACT = {"none": 0, "relu": 1, "gelu": 2, "sigmoid": 3}
 
 
@@ -53,6 +53,8 @@ SYMBOLS = {
     "dod_profile": (_I, [_P, _I]),
     "dod_profile_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dod_op_linear": (_I, [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "dod_op_linear_fp8": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "dod_op_quant_rows_fp8": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "dod_op_layernorm": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _I, _P]),
     "dod_op_attention_bf16": (_I, [_P, _P, _I, _I, _I, _F, _P]),
     "dod_op_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),

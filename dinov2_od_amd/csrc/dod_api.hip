@@ -19,7 +19,8 @@ namespace {
 struct WRef { const float* ptr; std::vector<int64_t> shape; size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; } };
 
 struct BLayer {
-  void *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;   // bf16 or fp32 by precision
+  void *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;   // bf16 or fp32 by precision (fp8 mode: Wqkv, W1 and the SwiGLU W2 are e4m3)
+  float *sqkv = nullptr, *s1 = nullptr, *s2 = nullptr;                 // fp8 mode: per-output-feature dequant scales
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
   float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
 };
@@ -84,7 +85,7 @@ int fail(const dod_handle* h, int code, const char* fmt, ...) {
 #define HIPCHK(h, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(h, DOD_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
 #define KCHK(h, x) do { int r_ = (x); if (r_) return fail(h, r_ == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "kernel launch failed (%d): %s", r_, #x); } while (0)
 
-enum { PC_GEMM_BF16 = 0, PC_ATTN_BF16 = 1, PC_GEMM_F32 = 2, PC_ATTN_F32 = 3, PC_LAYERNORM = 4, PC_OTHER = 5, PC_COUNT = 6 };
+enum { PC_GEMM_BF16 = 0, PC_ATTN_BF16 = 1, PC_GEMM_F32 = 2, PC_ATTN_F32 = 3, PC_LAYERNORM = 4, PC_OTHER = 5, PC_GEMM_FP8 = 6, PC_COUNT = 7 };
 struct ProfScope {
   dod_handle* h; hipStream_t s; int cls; double flops; hipEvent_t a = nullptr;
   ProfScope(dod_handle* h_, hipStream_t s_, int cls_, double flops_) : h(h_), s(s_), cls(cls_), flops(flops_) {
@@ -107,7 +108,9 @@ struct ProfScope {
   }
 };
 
-inline bool is_bf16(const dod_handle* h) { return h->cfg.precision == DOD_PREC_BF16; }
+inline bool is_fp8(const dod_handle* h) { return h->cfg.precision == DOD_PREC_FP8; }
+// operand dtype of everything that is not an fp8 GEMM: bf16 in both the bf16 and the fp8 mode
+inline bool is_bf16(const dod_handle* h) { return h->cfg.precision == DOD_PREC_BF16 || is_fp8(h); }
 inline size_t esz(const dod_handle* h) { return is_bf16(h) ? 2 : 4; }
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -178,6 +181,15 @@ struct Packer {
     if (launch_split3(src, cols, b, rows, cols, 1, s)) { if (!rc) rc = fail(h, DOD_ERR_HIP, "split3 launch failed"); return nullptr; }
     return b;
   }
+  // fp32 [rows, cols] -> e4m3 rows + per-row (output feature) scales
+  void* pack_fp8(const float* src, int rows, int cols, float** scale_out) {
+    if (!src) return nullptr;
+    unsigned char* q = alloc<unsigned char>((size_t)rows * cols); float* sc = alloc<float>(rows);
+    if (!q || !sc) return nullptr;
+    if (launch_quant_rows_fp8(src, 0, cols, rows, cols, q, cols, sc, s)) { if (!rc) rc = fail(h, DOD_ERR_HIP, "fp8 weight quantisation launch failed"); return nullptr; }
+    *scale_out = sc;
+    return q;
+  }
   // pack fp32 [rows, cols] (ld = cols) into the precision's operand dtype, K padded to cols_pad
   void* pack_operand(const float* src, int rows, int cols, int cols_pad, bool force_f32 = false) {
     if (!src) return nullptr;
@@ -237,16 +249,17 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
       HIPCHK(h, hipMemcpyAsync(L.bqkv + (size_t)t * D, b, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
     }
     if (P.rc) break;
-    L.Wqkv = P.pack_operand(cat, 3 * D, D, D);
+    const bool f8 = is_fp8(h);
+    L.Wqkv = f8 ? P.pack_fp8(cat, 3 * D, D, &L.sqkv) : P.pack_operand(cat, 3 * D, D, D);
     L.Wo = P.pack_operand(P.eff_weight(lp + "attention.output.dense", D, D), D, D, D);
     L.bo = P.eff_bias(lp + "attention.output.dense", D);
     if (c.swiglu) {
-      L.W1 = P.pack_operand(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, D);
+      L.W1 = f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, D);
       L.b1 = P.eff_bias(lp + "mlp.weights_in", 2 * F);
-      L.W2 = P.pack_operand(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, F);
+      L.W2 = f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, &L.s2) : P.pack_operand(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, F);
       L.b2 = P.eff_bias(lp + "mlp.weights_out", D);
     } else {
-      L.W1 = P.pack_operand(P.eff_weight(lp + "mlp.fc1", F, D), F, D, D);
+      L.W1 = f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.fc1", F, D), F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.fc1", F, D), F, D, D);
       L.b1 = P.eff_bias(lp + "mlp.fc1", F);
       L.W2 = P.pack_operand(P.eff_weight(lp + "mlp.fc2", D, F), D, F, F);
       L.b2 = P.eff_bias(lp + "mlp.fc2", D);
@@ -343,7 +356,7 @@ struct Carver {
 };
 
 struct DecWS { float *tgt, *t2, *att, *samp, *qkv, *proj, *ffn, *hb, *qd; void* mem_op; float* values; float* kv; bf16_t* a3; };
-struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; };
+struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; float* rs; };   // rs: fp8 mode, per-row activation scales [M]
 
 size_t carve_decoder(const dod_handle* h, Carver& c, int B, int N, DecWS* w, bool need_mem_op) {
   const dod_config& g = h->cfg;
@@ -377,6 +390,7 @@ size_t carve_backbone(const dod_handle* h, Carver& c, int B, int N, BbWS* w) {
   t.x = (float*)c.take(M * D * 4); t.y = c.take(M * D * es); t.qkv = c.take(M * 3 * D * es); t.ctx = c.take(M * D * es);
   t.hbuf = c.take(hb * es); t.gated = g.swiglu ? c.take(M * (size_t)g.ffn_hidden * es) : nullptr;
   t.mem = c.take(M * (size_t)(g.target_dim ? g.target_dim : g.hidden) * es);
+  t.rs = is_fp8(h) ? (float*)c.take(M * 4) : nullptr;
   if (w) *w = t;
   return c.off;
 }
@@ -408,6 +422,14 @@ int linear(dod_handle* h, bool bf, const void* A, int lda, const void* W, int ld
   if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "linear launch rejected (M=%d N=%d K=%d bf16=%d rc=%d)", M, N, K, (int)bf, r);
   return 0;
 }
+// fp8 linear: A_q [M,K] e4m3 with per-row scales, W_q [N,K] e4m3 with per-row (output feature) scales
+int linear8(dod_handle* h, const void* A, const float* a_scale, const void* W, const float* w_scale, int M, int N, int K, GemmEpi e, hipStream_t s) {
+  ProfScope ps(h, s, PC_GEMM_FP8, 2.0 * M * N * (double)K);
+  e.a_scale = a_scale; e.w_scale = w_scale;
+  int r = launch_gemm_fp8((const unsigned char*)A, K, (const unsigned char*)W, K, M, N, K, e, s);
+  if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "fp8 linear launch rejected (M=%d N=%d K=%d rc=%d)", M, N, K, r);
+  return 0;
+}
 GemmEpi epi(const float* bias, float* of32, void* obf, int ldc, int act = ACT_NONE, const float* scale = nullptr, const float* resid = nullptr, int ldr = 0) {
   GemmEpi e; memset(&e, 0, sizeof e);
   e.bias = bias; e.out_f32 = of32; e.out_bf16 = (bf16_t*)obf; e.ldc = ldc; e.act = act; e.scale = scale; e.resid = resid; e.ldr = ldr;
@@ -434,10 +456,16 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   tap(h, 0, ws.x, false, (size_t)M * D, s);
   const float scale = 1.0f / std::sqrt((float)(D / g.heads));
   float* yf = bf ? nullptr : (float*)ws.y; bf16_t* yb = bf ? (bf16_t*)ws.y : nullptr;
+  const bool f8 = is_fp8(h);   // LayerNorm / SwiGLU emit e4m3 rows + per-row scales (ws.rs) for the QKV / MLP linears
   for (int i = 0; i < g.layers; ++i) {
     const BLayer& L = h->L[i];
+    if (f8) {
+      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, nullptr, nullptr, s, (unsigned char*)ws.y, ws.rs)); }
+      rc = linear8(h, ws.y, ws.rs, L.Wqkv, L.sqkv, M, 3 * D, D, epi(L.bqkv, nullptr, ws.qkv, 3 * D), s); if (rc) return rc;
+    } else {
     { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, yf, yb, s)); }   // K3
     rc = linear(h, bf, ws.y, D, L.Wqkv, D, M, 3 * D, D, epi(L.bqkv, bf ? nullptr : (float*)ws.qkv, bf ? ws.qkv : nullptr, 3 * D), s); if (rc) return rc;  // K4
+    }
     if (bf) { ProfScope ps(h, s, PC_ATTN_BF16, 4.0 * B * (double)N * N * D); KCHK(h, launch_attn_bf16((const bf16_t*)ws.qkv, (bf16_t*)ws.ctx, B, N, g.heads, scale, s)); }    // K5
     else {
       ProfScope ps(h, s, PC_ATTN_F32, 4.0 * B * (double)N * N * D);
@@ -447,6 +475,19 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
       KCHK(h, launch_attn_f32(a, s));
     }
     rc = linear(h, bf, ws.ctx, D, L.Wo, D, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;   // K6
+    if (f8) {
+      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, (unsigned char*)ws.y, ws.rs)); }
+      if (g.swiglu) {
+        rc = linear8(h, ws.y, ws.rs, L.W1, L.s1, M, 2 * F, D, epi(L.b1, nullptr, ws.hbuf, 2 * F), s); if (rc) return rc;
+        KCHK(h, launch_swiglu_fp8((const bf16_t*)ws.hbuf, M, F, (unsigned char*)ws.gated, ws.rs, s));
+        rc = linear8(h, ws.gated, ws.rs, L.W2, L.s2, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
+      } else {   // GELU MLP: fc1 on fp8 operands, fc2 stays bf16 (its input is produced tile-wise by fc1's epilogue: no per-row scale)
+        rc = linear8(h, ws.y, ws.rs, L.W1, L.s1, M, F, D, epi(L.b1, nullptr, ws.hbuf, F, ACT_GELU), s); if (rc) return rc;
+        rc = linear(h, true, ws.hbuf, F, L.W2, F, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
+      }
+      tap(h, 1 + i, ws.x, false, (size_t)M * D, s);
+      continue;
+    }
     { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, yf, yb, s)); }
     if (g.swiglu) {                                                                                            // K7g
       rc = linear(h, bf, ws.y, D, L.W1, D, M, 2 * F, D, epi(L.b1, bf ? nullptr : (float*)ws.hbuf, bf ? ws.hbuf : nullptr, 2 * F), s); if (rc) return rc;
@@ -604,7 +645,7 @@ int dod_create(const dod_config* cfg, dod_handle** out) {
   const dod_config& c = *cfg;
   if (c.hidden <= 0 || c.layers <= 0 || c.heads <= 0 || c.hidden % c.heads) return fail(nullptr, DOD_ERR_INVALID, "bad backbone dims hidden=%d heads=%d layers=%d", c.hidden, c.heads, c.layers);
   if (c.hidden % 64) return fail(nullptr, DOD_ERR_INVALID, "hidden (%d) must be a multiple of 64", c.hidden);
-  if (c.ffn_hidden <= 0 || c.ffn_hidden % (c.precision == DOD_PREC_BF16 ? 64 : 4)) return fail(nullptr, DOD_ERR_INVALID, "ffn_hidden (%d) must be a multiple of %d in this precision", c.ffn_hidden, c.precision == DOD_PREC_BF16 ? 64 : 4);
+  if (c.ffn_hidden <= 0 || c.ffn_hidden % (c.precision != DOD_PREC_FP32 ? 64 : 4)) return fail(nullptr, DOD_ERR_INVALID, "ffn_hidden (%d) must be a multiple of %d in this precision", c.ffn_hidden, c.precision != DOD_PREC_FP32 ? 64 : 4);
   if (c.patch <= 0 || c.pos_grid <= 0) return fail(nullptr, DOD_ERR_INVALID, "bad patch/pos_grid");
   if (c.num_queries <= 0 || c.dec_hidden <= 0 || c.dec_heads <= 0 || c.dec_layers <= 0 || c.num_classes <= 0 || c.dim_feedforward <= 0) return fail(nullptr, DOD_ERR_INVALID, "bad decoder dims");
   if (c.dec_hidden % 64 || c.dim_feedforward % 4) return fail(nullptr, DOD_ERR_INVALID, "decoder hidden (%d) must be a multiple of 64, dim_feedforward (%d) of 4", c.dec_hidden, c.dim_feedforward);
@@ -612,7 +653,7 @@ int dod_create(const dod_config* cfg, dod_handle** out) {
   if (!c.target_dim && c.hidden != c.dec_hidden) return fail(nullptr, DOD_ERR_INVALID, "backbone width %d != decoder hidden %d and no projection", c.hidden, c.dec_hidden);
   if (c.use_deformable && (c.n_points <= 0 || c.n_points > 8)) return fail(nullptr, DOD_ERR_INVALID, "n_points must be 1..8");
   if (c.dec_layers > 64) return fail(nullptr, DOD_ERR_INVALID, "at most 64 decoder layers");
-  if (c.precision != DOD_PREC_FP32 && c.precision != DOD_PREC_BF16) return fail(nullptr, DOD_ERR_INVALID, "unknown precision %d", c.precision);
+  if (c.precision != DOD_PREC_FP32 && c.precision != DOD_PREC_BF16 && c.precision != DOD_PREC_FP8) return fail(nullptr, DOD_ERR_INVALID, "unknown precision %d", c.precision);
   dod_handle* h = new (std::nothrow) dod_handle();
   if (!h) return fail(nullptr, DOD_ERR_STATE, "out of host memory");
   h->cfg = c;
@@ -794,6 +835,22 @@ int dod_op_linear(int in_dtype, const void* A, int lda, const void* W, int ldw, 
   int r = in_dtype == DOD_BF16 ? launch_gemm_bf16((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, e, (hipStream_t)stream)
                                : launch_gemm_f32((const float*)A, lda, (const float*)W, ldw, M, N, K, e, (hipStream_t)stream);
   if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
+  return DOD_OK;
+}
+int dod_op_linear_fp8(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, int M, int N, int K,
+                      const float* bias, const float* scale, const float* resid, int ldr, void* out, int out_dtype, int ldc, int act,
+                      void* stream) {
+  if (!A || !W || !out || !a_scale || !w_scale) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  GemmEpi e = epi(bias, out_dtype == DOD_F32 ? (float*)out : nullptr, out_dtype == DOD_BF16 ? out : nullptr, ldc, act, scale, resid, ldr);
+  e.a_scale = a_scale; e.w_scale = w_scale;
+  int r = launch_gemm_fp8((const unsigned char*)A, lda, (const unsigned char*)W, ldw, M, N, K, e, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear_fp8 rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
+  return DOD_OK;
+}
+int dod_op_quant_rows_fp8(const void* x, int in_dtype, int ld, int rows, int cols, void* q, int ldq, float* scale, void* stream) {
+  if (!x || !q || !scale) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  int r = launch_quant_rows_fp8(x, in_dtype == DOD_BF16, ld, rows, cols, (unsigned char*)q, ldq, scale, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_quant_rows_fp8 rejected rows=%d cols=%d", rows, cols);
   return DOD_OK;
 }
 int dod_op_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps, int rows, int D, void* out, int out_dtype, void* stream) {

@@ -35,6 +35,12 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// four floats -> four OCP e4m3 bytes (v_cvt_pk_fp8_f32, round to nearest even), little-endian
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
 // exact-erf GELU (HF ACT2FN["gelu"], modeling_dinov2.py:288-296)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16
@@ -72,6 +78,8 @@ struct GemmEpi {
   const float* pos;       // [out_rows_per_img, N] (patch-embed only)
   int rows_per_img;
   int out_rows_per_img;
+  const float* a_scale;   // fp8 GEMM only: per-row (token) dequant scale of A, [M]; null otherwise
+  const float* w_scale;   // fp8 GEMM only: per-output-feature dequant scale of W, [N]
 };
 
 // ----------------------------------------------------------------------------- launchers (all enqueue on `s`, no sync)
@@ -80,10 +88,21 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
                      const GemmEpi& e, hipStream_t s);
 int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K,
                     const GemmEpi& e, hipStream_t s);
+// fp8 (OCP e4m3) operands, one byte per element, K contiguous; e.a_scale / e.w_scale are the dequant scales
+int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int ldw, int M, int N, int K,
+                    const GemmEpi& e, hipStream_t s);
+// rows x cols fp32 or bf16 -> e4m3 with one scale per row: scale[r] = amax_r / 448 (1 if the row is all zero),
+// q = rne_e4m3(x / scale[r]).  in_bf16: input element type.  ld in elements.
+// SwiGLU (silu(a) * b of the bf16 [rows, 2*Fh] input) -> e4m3 [rows, Fh] + per-row scale
+int launch_swiglu_fp8(const bf16_t* in, int rows, int Fh, unsigned char* q, float* scale, hipStream_t s);
+int launch_quant_rows_fp8(const void* x, int in_bf16, int ld, int rows, int cols, unsigned char* q, int ldq, float* scale,
+                          hipStream_t s);
 
 // rows x D LayerNorm, optional pre-add (y = LN(x + add)), fp32 statistics; out bf16 or fp32
+// out_fp8 / out_scale (both or neither): e4m3 row + per-row scale (amax / 448) instead of the fp32 / bf16 output
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
-                     int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s);
+                     int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s,
+                     unsigned char* out_fp8 = nullptr, float* out_scale = nullptr);
 
 // backbone attention, bf16 MFMA flash kernel, head_dim 64.  qkv [B*N, 3*D] bf16 -> ctx [B*N, D] bf16
 int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s);

@@ -1,0 +1,81 @@
+// Shared GEMM epilogue (bf16 and fp8 MFMA kernels): accumulators -> LDS tile -> whole-row HBM stores.
+#pragma once
+#include "dod_common.h"
+
+// 64-byte LDS rows read by 32-row MFMA lane groups: 16-B chunk ^= (row >> 2) & 3 (conflict-free ds_read_b128)
+__device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+
+// ---- epilogue, staged through LDS so that HBM sees whole rows ---------------------------------------
+// Phase 1 (stage_acc): a lane owns output row m and its register quads 4 consecutive n: it applies
+// bias / activation / LayerScale (float4 per-n parameter reads) and writes float4s into an fp32 LDS
+// tile [rows][cols] with a row pitch of cols*4 + 16 bytes (conflict-free ds_write_b128).
+// Phase 2 (drain_tile): every wave instruction moves ONE whole tile row: 16 B per lane from LDS, the
+// coalesced fp32 residual / position rows from HBM, and a coalesced store (1 KiB fp32 or 512 B bf16 per
+// instruction) -- instead of 32 rows x 16-B fragments per store instruction straight from the
+// accumulator layout, which made the epilogue cost 2x its HBM time.
+__device__ __forceinline__ void stage_acc(char* sm, int pitch, int row_l, int col_l, const f32x16& a, int lh) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int nl = col_l + 8 * g + 4 * lh;
+    *reinterpret_cast<float4*>(sm + row_l * pitch + nl * 4) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  }
+}
+
+// Per-thread epilogue parameters: with COLS/4 dividing the thread count, a thread drains the SAME four
+// columns of every row it visits, so bias / LayerScale are two float4 registers loaded once per tile.
+struct ColParams { float4 bias, scale, wscale; };   // wscale: per-output-feature dequant scale of an fp8 weight
+template <int COLS>
+__device__ __forceinline__ ColParams load_col_params(const GemmEpi& e, int n0, int N, int tid) {
+  ColParams c;
+  const int n = n0 + 4 * (tid % (COLS / 4));
+  const bool ok = n < N;
+  c.bias = (e.bias && ok) ? *reinterpret_cast<const float4*>(e.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  c.scale = (e.scale && ok) ? *reinterpret_cast<const float4*>(e.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+  c.wscale = (e.w_scale && ok) ? *reinterpret_cast<const float4*>(e.w_scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+  return c;
+}
+
+// rows of the LDS tile map to global rows through `rowmap` (row_l -> m)
+template <int ROWS, int COLS, int NT, typename RowMap>
+__device__ __forceinline__ void drain_tile(const char* sm, int pitch, const GemmEpi& e, const ColParams& cp, int M, int N,
+                                           int n0, int tid, RowMap rowmap) {
+  constexpr int C4 = COLS / 4;
+  static_assert(NT % C4 == 0, "a thread must keep its column group");
+  const int c4 = tid % C4;
+  const int n = n0 + 4 * c4;
+  if (n >= N) return;
+#pragma unroll
+  for (int row_l = tid / C4; row_l < ROWS; row_l += NT / C4) {
+    const int m = rowmap(row_l);
+    if (m >= M) continue;
+    float4 v = *reinterpret_cast<const float4*>(sm + row_l * pitch + c4 * 16);
+    if (e.a_scale) {   // fp8 operands: (A_q W_q^T)[m][n] * a_scale[m] * w_scale[n]
+      const float sa = e.a_scale[m];
+      v.x *= sa * cp.wscale.x; v.y *= sa * cp.wscale.y; v.z *= sa * cp.wscale.z; v.w *= sa * cp.wscale.w;
+    }
+    v.x += cp.bias.x; v.y += cp.bias.y; v.z += cp.bias.z; v.w += cp.bias.w;
+    if (e.act == ACT_GELU) { v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w); }
+    else if (e.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    v.x *= cp.scale.x; v.y *= cp.scale.y; v.z *= cp.scale.z; v.w *= cp.scale.w;
+    size_t orow = (size_t)m;
+    if (e.rows_per_img > 0) {
+      const int b = m / e.rows_per_img, p = m - b * e.rows_per_img;
+      orow = (size_t)b * e.out_rows_per_img + 1 + p;
+      const float4 p4 = *reinterpret_cast<const float4*>(e.pos + (size_t)(1 + p) * N + n);
+      v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+    }
+    if (e.resid) {
+      const float4 r4 = *reinterpret_cast<const float4*>(e.resid + orow * e.ldr + n);
+      v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+    }
+    if (e.out_f32) {
+      *reinterpret_cast<float4*>(e.out_f32 + orow * e.ldc + n) = v;
+    } else {
+      uint2 o;
+      o.x = pack2bf(v.x, v.y);
+      o.y = pack2bf(v.z, v.w);
+      *reinterpret_cast<uint2*>(e.out_bf16 + orow * e.ldc + n) = o;
+    }
+  }
+}
+

@@ -1,0 +1,234 @@
+// fp8 (OCP e4m3) MFMA GEMM for the ViT-g/14 fp8 configuration (BASELINE.json configs[4]):
+//   C[M,N] = (Aq[M,K] * Wq[N,K]^T) * a_scale[m] * w_scale[n]  (+ the usual fused epilogue),
+// Aq / Wq one byte per element, K contiguous; per-token scales from the producing LayerNorm / SwiGLU kernel, per-output-
+// feature scales from weight packing.  Replaces the same nn.Linear sites as gemm_bf16.hip (modeling_dinov2.py:199-201,
+// 281-314) when the handle's precision is fp8.
+//
+// Same skeleton as the 256x128 bf16 kernel: 8 waves (4 x 2) of 64x64, transposed product (a lane owns an output row),
+// LDS-DMA into a 3-slot ring, two workgroups per CU, one raw barrier per K-tile -- but a K-tile is 64 BYTES = 64 fp8
+// elements per row (the same 24 KiB of staging now carries twice the K), and one v_mfma_f32_32x32x64_f8f6f4 (2x the
+// bf16 MAC rate) consumes a whole K-tile per 32x32 block: lane (row r = lane&31, half h = lane>>5) supplies bytes
+// [32h, 32h+32) of row r, i.e. the two 16-B chunks 2h and 2h+1 (swizzled as chunk ^ (r>>2)&3, conflict-free b128 reads).
+// Both operands use the same byte->lane map, so the k order inside the instruction is irrelevant to the dot product.
+#include "dod_common.h"
+#include "gemm_epi.h"
+#include <cstdlib>
+
+#define F8M 256
+#define F8N 128
+#define F8K 64                                  // bytes (= elements) per row per K-tile
+#define F8_STAGE ((F8M + F8N) * F8K)            // 24 KiB
+#define F8_SLOTS 3
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 4) void gemm_fp8_256x128_kernel(const unsigned char* __restrict__ A, int lda,
+                                                                  const unsigned char* __restrict__ W, int ldw,
+                                                                  int M, int N, int K, GemmEpi e, int GM) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_m = (M + F8M - 1) / F8M, tiles_n = (N + F8N - 1) / F8N;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {   // XCD-aware bijective remap, then GM m-tiles deep groups inside each XCD's run (as in gemm_bf16.hip)
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  {
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = bid - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
+  const int m0 = tm * F8M, n0 = tn * F8N;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // per K-tile a wave issues 2 pieces of A and 1 of W; piece = 16 rows x 64 B, lane -> (row = lane>>2, chunk = lane&3)
+  const unsigned char* gA0; const unsigned char* gA1; const unsigned char* gW0;
+  {
+    auto src = [&](const unsigned char* base, int ld, int r0, int piece, int lim) {
+      const int rl = piece * 16 + (lane >> 2);
+      int r = r0 + rl; r = r < lim ? r : lim - 1;
+      return base + (size_t)r * ld + swz64(rl, lane & 3) * 16;
+    };
+    gA0 = src(A, lda, m0, wid * 2, M); gA1 = src(A, lda, m0, wid * 2 + 1, M);
+    gW0 = src(W, ldw, n0, wid, N);
+  }
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+#define STAGE8(slot_, k0)                                                                                  \
+  {                                                                                                        \
+    char* sA_ = smem + (slot_) * F8_STAGE + wu * 2048;                                                     \
+    char* sW_ = smem + (slot_) * F8_STAGE + F8M * F8K + wu * 1024;                                         \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (k0)), (lptr_t)(sA_), 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (k0)), (lptr_t)(sA_ + 1024), 16, 0, 0);                \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sW_), 16, 0, 0);                       \
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = K / F8K;
+  const int lr = lane & 31, lh = lane >> 5;
+  STAGE8(0, 0)
+  if (nk > 1) STAGE8(1, F8K)
+  int offA[2], offW[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int row = wm * 64 + i * 32 + lr; offA[i] = row * 64 + swz64(row, 2 * lh) * 16; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offW[j] = F8M * F8K + row * 64 + swz64(row, 2 * lh) * 16; }
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) {
+      const int ns = slot >= 1 ? slot - 1 : 2;
+      STAGE8(ns, (kt + 2) * F8K)
+    }
+    const char* st = smem + slot * F8_STAGE;
+    i32x8 af[2], wf[2];
+#pragma unroll
+    // the fragments are read as ushort vectors, like the bf16 kernels: typed as int the reads "may alias" the pending
+    // LDS-DMA writes and hipcc drains the ring (vmcnt(0)) in every iteration
+    for (int i = 0; i < 2; ++i) {
+      const i32x4 lo = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + offA[i]));
+      const i32x4 hi = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ 16)));   // chunk 2h+1 = (2h ^ s) ^ 1
+      af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const i32x4 lo = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + offW[j]));
+      const i32x4 hi = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ 16)));
+      wf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)   // cbsz = blgp = 0: both operands e4m3; scale operands 0 -> the unscaled instruction form
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0, 0, 0);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  // epilogue: two passes of 128 tile rows through a 128 x 128 fp32 LDS tile; dequant scales applied in drain_tile
+  constexpr int PITCH = F8N * 4 + 16;
+  const ColParams cp = load_col_params<F8N>(e, n0, N, tid);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      stage_acc(smem, PITCH, wm * 32 + lr, wn * 64 + j * 32, acc[pass][j], lh);
+    __syncthreads();
+    drain_tile<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
+                              [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+  }
+}
+
+static constexpr int LDS8 = (128 * (F8N * 4 + 16)) > F8_SLOTS * F8_STAGE ? (128 * (F8N * 4 + 16)) : F8_SLOTS * F8_STAGE;
+
+int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int ldw, int M, int N, int K,
+                    const GemmEpi& e, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0) return 1;
+  if (K % F8K != 0 || N % 4 != 0 || lda % 16 != 0 || ldw % 16 != 0 || e.ldc % 4 != 0) return 2;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) return 2;
+  if (e.resid && e.ldr % 4 != 0) return 2;
+  if (!e.out_f32 && !e.out_bf16) return 2;
+  if (!e.a_scale || !e.w_scale) return 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+    attr_set = true;
+  }
+  static const char* gme = getenv("DINODET_GEMM_GM");
+  const int gm = gme ? atoi(gme) : (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2));
+  const int tiles = ((M + F8M - 1) / F8M) * ((N + F8N - 1) / F8N);
+  hipLaunchKernelGGL(gemm_fp8_256x128_kernel, dim3(tiles), dim3(512), LDS8, s, A, lda, W, ldw, M, N, K, e, gm);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// ---------------------------------------------------------------------------------------------- row quantisation
+// One wave per row: amax by wave reduction, scale = amax / 448 (e4m3 max finite), q = rne(x / scale).
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restrict__ xin, int ld, int rows, int cols,
+                                                             unsigned char* __restrict__ q, int ldq,
+                                                             float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  auto ld4 = [&](int c) -> float4 {
+    if (IN_BF16) {
+      const uint2 u = *reinterpret_cast<const uint2*>((const bf16_t*)xin + (size_t)row * ld + c);
+      return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                         __uint_as_float(u.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>((const float*)xin + (size_t)row * ld + c);
+  };
+  float amax = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const float4 v = ld4(c);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const float4 v = ld4(c);
+    *reinterpret_cast<unsigned*>(q + (size_t)row * ldq + c) = pack4_fp8(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+  }
+}
+
+int launch_quant_rows_fp8(const void* x, int in_bf16, int ld, int rows, int cols, unsigned char* q, int ldq, float* scale,
+                          hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 1;
+  if (cols % 4 != 0 || ld % 4 != 0 || ldq % 4 != 0) return 2;
+  const int blocks = (rows + 3) / 4;
+  if (in_bf16) hipLaunchKernelGGL(quant_rows_fp8_kernel<true>, dim3(blocks), dim3(256), 0, s, x, ld, rows, cols, q, ldq, scale);
+  else hipLaunchKernelGGL(quant_rows_fp8_kernel<false>, dim3(blocks), dim3(256), 0, s, x, ld, rows, cols, q, ldq, scale);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// SwiGLU -> fp8 rows (ViT-g MLP, modeling_dinov2.py:310-314): one wave per row, two passes over the row's 4*Fh bytes
+// (the second hits L2): amax of silu(a)*b, then quantise.
+__global__ __launch_bounds__(256) void swiglu_fp8_kernel(const bf16_t* __restrict__ in, int rows, int Fh,
+                                                         unsigned char* __restrict__ q, float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* pa = in + (size_t)row * 2 * Fh;
+  const bf16_t* pb = pa + Fh;
+  auto val4 = [&](int c) -> float4 {
+    const uint2 ua = *reinterpret_cast<const uint2*>(pa + c), ub = *reinterpret_cast<const uint2*>(pb + c);
+    const float a0 = __uint_as_float(ua.x << 16), a1 = __uint_as_float(ua.x & 0xffff0000u), a2 = __uint_as_float(ua.y << 16), a3 = __uint_as_float(ua.y & 0xffff0000u);
+    const float b0 = __uint_as_float(ub.x << 16), b1 = __uint_as_float(ub.x & 0xffff0000u), b2 = __uint_as_float(ub.y << 16), b3 = __uint_as_float(ub.y & 0xffff0000u);
+    return make_float4(a0 / (1.0f + expf(-a0)) * b0, a1 / (1.0f + expf(-a1)) * b1, a2 / (1.0f + expf(-a2)) * b2, a3 / (1.0f + expf(-a3)) * b3);
+  };
+  float amax = 0.f;
+  for (int c = lane * 4; c < Fh; c += 256) {
+    const float4 v = val4(c);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+  for (int c = lane * 4; c < Fh; c += 256) {
+    const float4 v = val4(c);
+    *reinterpret_cast<unsigned*>(q + (size_t)row * Fh + c) = pack4_fp8(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+  }
+}
+int launch_swiglu_fp8(const bf16_t* in, int rows, int Fh, unsigned char* q, float* scale, hipStream_t s) {
+  if (rows <= 0 || Fh <= 0) return 1;
+  if (Fh % 4 != 0) return 2;
+  hipLaunchKernelGGL(swiglu_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in, rows, Fh, q, scale);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}

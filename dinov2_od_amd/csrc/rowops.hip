@@ -12,7 +12,8 @@
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, int rows, int D, float* __restrict__ out_f32,
-                                                        bf16_t* __restrict__ out_bf16) {
+                                                        bf16_t* __restrict__ out_bf16, unsigned char* __restrict__ out_fp8,
+                                                        float* __restrict__ out_scale) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -41,6 +42,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  if (out_fp8) {   // fp8 operand for the next GEMM: normalised row kept in registers, one scale per row (amax / 448)
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nc) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+        const float4 b = reinterpret_cast<const float4*>(beta)[c];
+        v[i].x = (v[i].x - mean) * rstd * g.x + b.x;
+        v[i].y = (v[i].y - mean) * rstd * g.y + b.y;
+        v[i].z = (v[i].z - mean) * rstd * g.z + b.z;
+        v[i].w = (v[i].w - mean) * rstd * g.w + b.w;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+      }
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) out_scale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nc) reinterpret_cast<unsigned*>(out_fp8 + (size_t)row * D)[c] = pack4_fp8(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i) {
     const int c = lane + 64 * i;
@@ -64,11 +91,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
-                     int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s) {
+                     int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s, unsigned char* out_fp8,
+                     float* out_scale) {
   if (rows <= 0) return 1;
   if (D % 4 != 0 || D > 256 * LN_MAXC) return 2;
+  if ((out_fp8 == nullptr) != (out_scale == nullptr)) return 2;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, add, gamma, beta, eps, rows, D,
-                     out_f32, out_bf16);
+                     out_f32, out_bf16, out_fp8, out_scale);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -140,7 +140,7 @@ class Engine:
         return det
 
     # ------------------------------------------------------------------ per-kernel timing (bench roofline leg)
-    PROFILE_CLASSES = {"gemm_bf16": 0, "attn_bf16": 1, "gemm_f32": 2, "attn_f32": 3, "layernorm": 4}
+    PROFILE_CLASSES = {"gemm_bf16": 0, "attn_bf16": 1, "gemm_f32": 2, "attn_f32": 3, "layernorm": 4, "gemm_fp8": 6}
 
     def profile(self, enable):
         nat.check(self._lib.dod_profile(self._h, int(bool(enable))), self._h)

@@ -42,8 +42,11 @@ enum dod_status {
 
 enum dod_precision {
   DOD_PREC_FP32 = 0,        /* exact-fp32 MFMA/VALU everywhere: the mode gated at 1e-3 parity  */
-  DOD_PREC_BF16 = 1         /* bf16 MFMA operands in the backbone + value projection, fp32
+  DOD_PREC_BF16 = 1,        /* bf16 MFMA operands in the backbone + value projection, fp32
                                accumulate / residual stream / LayerNorm / softmax / decoder     */
+  DOD_PREC_FP8 = 2          /* as BF16, with the QKV / MLP-in (/ SwiGLU MLP-out) linears on OCP e4m3 MFMA operands:
+                               per-token activation scales from the producing LayerNorm / SwiGLU kernel, per-output-
+                               feature weight scales (BASELINE configs[4]: ViT-g/14 fp8)          */
 };
 
 /* Shapes.  Backbone fields mirror HF Dinov2Config as used by dinov2_backbone.py:11-27; decoder
@@ -120,7 +123,7 @@ int dod_set_tap(dod_handle* h, int stage, float* dst);
  * forward (used by bench.py's roofline leg; adds an event pair per launch, so it is off in the timed
  * region).  dod_profile(h, 1) clears and enables, forwards accumulate, dod_profile_read() waits for the
  * events and returns summed milliseconds, algorithmic FLOPs (2*M*N*K resp. 4*B*N*N*D) and launches.
- * cls: 0 bf16 MFMA GEMM, 1 bf16 flash attention, 2 fp32 MFMA GEMM, 3 fp32 attention, 4 backbone LayerNorm. */
+ * cls: 0 bf16 MFMA GEMM, 1 bf16 flash attention, 2 fp32 MFMA GEMM, 3 fp32 attention, 4 backbone LayerNorm, 6 fp8 MFMA GEMM. */
 int dod_profile(dod_handle* h, int enable);
 int dod_profile_read(dod_handle* h, int cls, double* ms, double* flops, int* launches);
 
@@ -132,6 +135,15 @@ enum dod_act { DOD_ACT_NONE = 0, DOD_ACT_RELU = 1, DOD_ACT_GELU = 2, DOD_ACT_SIG
 int dod_op_linear(int in_dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                   const float* bias, const float* scale, const float* resid, int ldr,
                   void* out, int out_dtype, int ldc, int act, void* stream);
+/* fp8 (OCP e4m3) operands, one byte per element: out = act((Aq Wq^T) * a_scale[m] * w_scale[n] + bias) * scale + resid.
+ * K % 64 == 0, lda / ldw in bytes, % 16 == 0.  The ViT-g fp8 configuration's linears (BASELINE configs[4]). */
+int dod_op_linear_fp8(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale,
+                      int M, int N, int K, const float* bias, const float* scale, const float* resid, int ldr,
+                      void* out, int out_dtype, int ldc, int act, void* stream);
+/* x [rows, cols] (fp32 or bf16, ld in elements) -> q e4m3 [rows, ldq] and scale[rows] = amax_row / 448 (1 for an all-zero
+ * row); q = round-to-nearest-even e4m3 of x / scale */
+int dod_op_quant_rows_fp8(const void* x, int in_dtype, int ld, int rows, int cols, void* q, int ldq, float* scale,
+                          void* stream);
 /* out = LayerNorm(x + add) ; add may be NULL */
 int dod_op_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, void* out, int out_dtype, void* stream);

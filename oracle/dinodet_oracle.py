@@ -27,6 +27,8 @@ outputs of the reference itself, imported once in the authoring container by
 tell which of two fp32 implementations is closer to the exact result).
 `emulate_bf16=True` rounds GEMM/attention operands to bf16 at the points where the
 HIP fast path does (DESIGN.md "precision modes"); accumulation stays fp32.
+`emulate_bf16="fp8"` additionally fake-quantises the operands of the linears the fp8 mode
+runs on e4m3 MFMA (per-token / per-output-feature scales, torch.float8_e4m3fn rounding).
 """
 import math
 import torch
@@ -60,14 +62,24 @@ class _SD:
         return key in self.sd
 
 
-def _linear(x, w, b, emu):
-    if emu:
+def _q8(t):
+    """per-row OCP e4m3 fake quantisation as the HIP fp8 path defines it (gemm_fp8.hip): scale = amax / 448 (1 for an
+    all-zero row), q = rne_e4m3(t * (1 / scale)); returns the dequantised values q * scale"""
+    amax = t.abs().amax(dim=-1, keepdim=True)
+    sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    return (t * (1.0 / sc)).to(torch.float8_e4m3fn).to(t.dtype) * sc
+
+
+def _linear(x, w, b, emu, fp8=False):
+    if emu and fp8:
+        x, w = _q8(x), _q8(w)          # per-token activation scales, per-output-feature weight scales
+    elif emu:
         x, w = _bf(x), _bf(w)
     y = x @ w.t()
     return y if b is None else y + b
 
 
-def _maybe_lora_linear(sd, prefix, x, alpha, emu):
+def _maybe_lora_linear(sd, prefix, x, alpha, emu, fp8=False):
     """nn.Linear, or LoraLinear (dino_detector/utils.py:68-70):
     linear(x) + alpha * lora_B(lora_A(x)).  With `emu` the HIP path's merged
     weight W' = W + alpha*B@A (fp32, then bf16) is what is emulated."""
@@ -75,9 +87,9 @@ def _maybe_lora_linear(sd, prefix, x, alpha, emu):
         w, b = sd(prefix + ".linear.weight"), sd(prefix + ".linear.bias")
         A, Bm = sd(prefix + ".lora_A.weight"), sd(prefix + ".lora_B.weight")
         if emu:
-            return _linear(x, w + alpha * (Bm @ A), b, True)
+            return _linear(x, w + alpha * (Bm @ A), b, True, fp8)
         return x @ w.t() + b + alpha * ((x @ A.t()) @ Bm.t())
-    return _linear(x, sd(prefix + ".weight"), sd(prefix + ".bias"), emu)
+    return _linear(x, sd(prefix + ".weight"), sd(prefix + ".bias"), emu, fp8)
 
 
 def _layernorm(x, w, b, eps):
@@ -172,9 +184,10 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
         a = bb.lora_alpha
         # K3-K6   modeling_dinov2.py:361-370
         y = _layernorm(h, sd(lp + "norm1.weight"), sd(lp + "norm1.bias"), bb.ln_eps)
-        q = _maybe_lora_linear(sd, lp + "attention.attention.query", y, a, emu)
-        k = _maybe_lora_linear(sd, lp + "attention.attention.key", y, a, emu)
-        v = _maybe_lora_linear(sd, lp + "attention.attention.value", y, a, emu)
+        f8 = emu == "fp8"   # fp8 mode: QKV / MLP-in (/ SwiGLU MLP-out) linears on e4m3 operands, the rest as the bf16 mode
+        q = _maybe_lora_linear(sd, lp + "attention.attention.query", y, a, emu, f8)
+        k = _maybe_lora_linear(sd, lp + "attention.attention.key", y, a, emu, f8)
+        v = _maybe_lora_linear(sd, lp + "attention.attention.value", y, a, emu, f8)
         if emu:
             q, k, v = _bf(q), _bf(k), _bf(v)
         q = q.view(B, N, nh, dh).transpose(1, 2)
@@ -197,12 +210,14 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
         # K7 / K7g   modeling_dinov2.py:373-380
         y = _layernorm(h, sd(lp + "norm2.weight"), sd(lp + "norm2.bias"), bb.ln_eps)
         if bb.swiglu:
-            z = _maybe_lora_linear(sd, lp + "mlp.weights_in", y, a, emu)
+            z = _maybe_lora_linear(sd, lp + "mlp.weights_in", y, a, emu, f8)
+            if f8:
+                z = _bf(z)              # the fp8 path stores the MLP-in output in bf16 before the SwiGLU kernel
             x1, x2 = z.chunk(2, dim=-1)
             z = F.silu(x1) * x2
-            z = _maybe_lora_linear(sd, lp + "mlp.weights_out", z, a, emu)
+            z = _maybe_lora_linear(sd, lp + "mlp.weights_out", z, a, emu, f8)
         else:
-            z = _maybe_lora_linear(sd, lp + "mlp.fc1", y, a, emu)
+            z = _maybe_lora_linear(sd, lp + "mlp.fc1", y, a, emu, f8)
             z = 0.5 * z * (1.0 + torch.erf(z / math.sqrt(2.0)))   # exact-erf GELU
             z = _maybe_lora_linear(sd, lp + "mlp.fc2", z, a, emu)
         h = z * sd(lp + "layer_scale2.lambda1") + h

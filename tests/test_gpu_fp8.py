@@ -1,0 +1,139 @@
+"""fp8 (OCP e4m3) operators of the ViT-g fp8 configuration (BASELINE configs[4]): row quantisation and the fp8 MFMA GEMM
+against torch's float8_e4m3fn on the CPU.  Quantised bytes are bit-exact; the GEMM is held to the exact products of the same
+fp8 operands within ACC_TOL: v_mfma_f32_32x32x64_f8f6f4 sums its 64 products with a narrower internal alignment than a chain of
+fp32 FMAs (measured 2e-5 relative at K = 64 where an fp32 chain gives 1e-7) -- a property of the instruction, not of the kernel."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dinov2_od_amd import _native as nat, synth
+from tests.cases import rel_err
+
+pytestmark = pytest.mark.gpu
+ACC_TOL = 1e-4
+
+
+def _n(tag, shape, std=1.0):
+    return synth.normal(7, tag, shape, std)
+
+
+def quant_ref(x):
+    """per-row e4m3 quantisation as the kernels define it: scale = amax / 448, q = rne_e4m3(x * (1 / scale))"""
+    x = x.float()
+    amax = x.abs().amax(dim=1, keepdim=True)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    q = (x * (1.0 / scale)).to(torch.float8_e4m3fn)
+    return q, scale[:, 0]
+
+
+def quant_gpu(x):
+    L = nat.lib()
+    rows, cols = x.shape
+    q = torch.empty(rows, cols, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    nat.check(L.dod_op_quant_rows_fp8(nat.ptr(x), nat.DOD_BF16 if x.dtype == torch.bfloat16 else nat.DOD_F32, x.stride(0), rows, cols,
+                                      nat.ptr(q), cols, nat.ptr(sc), nat.stream_ptr()))
+    return q, sc
+
+
+@pytest.mark.parametrize("rows,cols,dt", [(5, 64, torch.float32), (1000, 1536, torch.float32), (333, 4096, torch.bfloat16), (2, 8, torch.float32)])
+def test_quant_rows_is_bit_exact(rows, cols, dt):
+    x = torch.from_numpy(_n(f"q.{rows}.{cols}", (rows, cols), 2.0)).to(dt)
+    x[0, :] *= 1e-3          # a small-magnitude row
+    if rows > 2:
+        x[2, :] = 0          # an all-zero row -> scale 1, zeros
+    qr, sr = quant_ref(x)
+    qg, sg = quant_gpu(x.cuda())
+    assert torch.equal(sg.cpu(), sr)
+    assert torch.equal(qg.cpu(), qr.view(torch.uint8))
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 64), (1000, 384, 1536), (2740, 4608, 1536), (4110 + 7, 1536, 4096), (300, 100, 128)])
+def test_linear_fp8_all_epilogues(M, N, K):
+    L = nat.lib()
+    A = torch.from_numpy(_n(f"f8.A.{M}.{K}", (M, K)))
+    W = torch.from_numpy(_n(f"f8.W.{N}.{K}", (N, K), 0.05))
+    qa, sa = quant_ref(A)
+    qw, sw = quant_ref(W)
+    ref = (qa.double() @ qw.double().t()) * sa.double()[:, None] * sw.double()[None, :]   # exact products of the fp8 operands
+    bias, scale, resid = torch.from_numpy(_n("f8.b", (N,))), 1 + torch.from_numpy(_n("f8.s", (N,), 0.1)), torch.from_numpy(_n("f8.r", (M, N)))
+    qa_d, qw_d = qa.view(torch.uint8).cuda(), qw.view(torch.uint8).cuda()
+    sa_d, sw_d = sa.cuda(), sw.cuda()
+
+    def run(bias=None, scale=None, resid=None, act="none", out_dtype=torch.float32):
+        out = torch.empty(M, N, dtype=out_dtype, device="cuda")
+        nat.check(L.dod_op_linear_fp8(nat.ptr(qa_d), K, nat.ptr(sa_d), nat.ptr(qw_d), K, nat.ptr(sw_d), M, N, K, nat.ptr(bias), nat.ptr(scale),
+                                      nat.ptr(resid), N if resid is not None else 0, nat.ptr(out),
+                                      nat.DOD_BF16 if out_dtype == torch.bfloat16 else nat.DOD_F32, N, nat.ACT[act], nat.stream_ptr()))
+        return out
+
+    err = rel_err(run().cpu().numpy(), ref.numpy())
+    print(f"fp8 gemm M={M} N={N} K={K}: rel err vs exact products {err:.2e}")
+    assert err < ACC_TOL
+    want = F.gelu(ref + bias.double())
+    assert rel_err(run(bias.cuda(), act="gelu", out_dtype=torch.bfloat16).float().cpu().numpy(), want.numpy()) < 2 ** -7
+    want = (ref + bias.double()) * scale.double() + resid.double()
+    assert rel_err(run(bias.cuda(), scale.cuda(), resid.cuda()).cpu().numpy(), want.numpy()) < ACC_TOL
+
+
+def test_linear_fp8_rejects_bad_shapes():
+    L = nat.lib()
+    z = torch.zeros(64, 96, dtype=torch.uint8, device="cuda")
+    s = torch.ones(64, device="cuda")
+    o = torch.empty(64, 64, device="cuda")
+    with pytest.raises(ValueError):   # K % 64
+        nat.check(L.dod_op_linear_fp8(nat.ptr(z), 96, nat.ptr(s), nat.ptr(z), 96, nat.ptr(s), 64, 64, 96, None, None, None, 0, nat.ptr(o), nat.DOD_F32, 64, 0, nat.stream_ptr()))
+
+
+@pytest.mark.parametrize("variant", ["giant", "large"])
+def test_fp8_mode_backbone_two_blocks_vs_fp8_faithful_oracle(variant):
+    """BASELINE configs[4] shape at reduced depth: ViT-g (hidden 1536, 24 heads, SwiGLU 4096: QKV, MLP-in and MLP-out on e4m3
+    operands) and ViT-L (GELU: QKV and fc1 on e4m3, fc2 bf16), 224x224, through the drop-in module with precision="fp8".
+    e4m3 has a 3-bit mantissa: every product carries ~3 % error and a linear's output ~3-4 % whatever K, so the features of
+    even two blocks sit ~1e-1 (rel-L2) from the fp32 reference -- for the HIP path and for the oracle evaluated with the SAME
+    operand quantisation (per-token / per-output-feature scales) alike.  The two cannot agree tightly either: a bf16-level
+    difference (3e-3) in a LayerNorm output flips ~5 % of its e4m3 roundings by a whole 6 % step.  Criteria: the quantised
+    operators are exact (tests above); end to end the HIP path is (a) no further from the fp32 reference than the fp8-faithful
+    oracle is (x1.3) and (b) closer to that oracle than the oracle is to fp32."""
+    from dinov2_od_amd.config import BackboneConfig, DecoderConfig, num_tokens
+    from oracle import dinodet_oracle as orc
+    from tests import gpu_util as G
+    from tests.cases import rel_l2
+    hidden, heads, swiglu = (1024, 16, False) if variant == "large" else (1536, 24, True)
+    bb = BackboneConfig(hidden=hidden, layers=2, heads=heads, swiglu=swiglu, lora_r=2, lora_alpha=1.0, target_dim=768)
+    dc = DecoderConfig(num_queries=100, hidden_dim=768, nheads=8, num_layers=3, num_classes=91, dim_feedforward=1024,
+                       n_points=2, use_deformable=True)
+    sd = synth.detector_state_dict(bb, dc, seed=1)
+    x = synth.make_pixels(2, 224, 224, seed=0)
+    m = G.make_detector(bb, dc, "fp8", f"facebook/dinov2-{variant}")
+    N = num_tokens(224, 224)
+    eng = m._get_engine()
+    b0 = eng.set_tap(1, (2, N, hidden), "cuda:0")
+    mem = eng.set_tap(1000, (2, N, 768), "cuda:0")
+    out = m(G.to_gpu(x))
+    G.sync()
+    assert out["pred_logits"].shape == (2, 100, 91) and torch.isfinite(out["pred_logits"]).all()
+    taps = {}
+    want = orc.detector_forward(sd, bb, dc, x, emulate_bf16="fp8", taps=taps)
+    exact = orc.detector_forward(sd, bb, dc, x)
+    e_b0 = rel_err(b0.cpu().numpy(), taps["block0"].numpy())
+    e_mem = rel_l2(mem.cpu().numpy(), want["features"].numpy())
+    d_mem = rel_l2(mem.cpu().numpy(), exact["features"].numpy())
+    d_emu = rel_l2(want["features"].numpy(), exact["features"].numpy())
+    print(f"fp8 {variant}: block0 vs fp8 oracle {e_b0:.2e} (max), features vs fp8 oracle {e_mem:.2e} (L2), "
+          f"features vs fp32 reference {d_mem:.2e} (fp8 oracle itself {d_emu:.2e})")
+    assert e_b0 < 4e-2
+    assert d_mem < 1.3 * d_emu + 1e-2 and d_mem < 0.2           # as far from fp32 as the fp8-faithful oracle is
+    assert e_mem < 0.7 * d_emu + 1e-2                           # and closer to that oracle than fp32 is
+    assert rel_l2(out["pred_boxes"].cpu().numpy(), exact["pred_boxes"].numpy()) < 0.5
+
+
+def test_fp8_mode_rejects_unsupported_dims():
+    from dinov2_od_amd.config import BackboneConfig
+    from tests import cases, gpu_util as G
+    bb = BackboneConfig(hidden=128, layers=1, heads=2, swiglu=True, pos_grid=5, lora_r=0, target_dim=0)   # SwiGLU width 344: not % 64
+    dc = cases.dec_cfg(True)
+    with pytest.raises(ValueError):
+        m = G.make_detector(bb, dc, "fp8")
+        m(torch.zeros(1, 3, 70, 70, device="cuda"))

@@ -65,7 +65,8 @@ def test_create_validates_arguments(lib):
     bad.target_dim = 128                                         # != decoder hidden 256
     assert lib.dod_create(C.byref(bad), C.byref(h2)) == 1
     with pytest.raises(ValueError):
-        make_config(bb, dc, "fp8")
+        make_config(bb, dc, "fp4")
+    assert make_config(bb, dc, "fp8").precision == 2          # DOD_PREC_FP8
 
 
 @pytest.mark.parametrize("deform", [True, False])
