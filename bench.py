@@ -120,7 +120,11 @@ def main():
 
     from dinov2_od_amd import dist as ddist
     from dinov2_od_amd.config import flops_per_image
-    rank, world, local = ddist.init_from_env("nccl" if torch.cuda.is_available() else None)
+    # RCCL ("nccl") is the backend of record; DINODET_DIST_BACKEND=gloo only exists to rehearse the N > 1 control flow on a
+    # one-GPU box (all ranks on cuda:0)
+    rank, world, local = ddist.init_from_env(os.environ.get("DINODET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else None))
+    if os.environ.get("DINODET_DIST_BACKEND") == "gloo":
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     if world != a.gpus:
