@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="vitb518", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     a = ap.parse_args()
@@ -210,8 +210,8 @@ def main():
     global_batch = B_local * world
     ips = global_batch * a.steps / dt
     fpi = flops_per_image(bb, dc, R, R)
-    dom = {"bf16": "gemm_bf16", "fp32": "gemm_f32", "fp8": "gemm_fp8"}[a.precision]
-    peak = {"bf16": PEAK_BF16, "fp32": PEAK_F32, "fp8": PEAK_FP8}[a.precision]
+    dom = {"bf16": "gemm_bf16", "fp32": "gemm_f32", "fp8": "gemm_fp8", "bf16x3": "gemm_bf16"}[a.precision]
+    peak = {"bf16": PEAK_BF16, "fp32": PEAK_F32, "fp8": PEAK_FP8, "bf16x3": PEAK_BF16}[a.precision]
     d = prof[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) if d["ms"] > 0 else 0.0
     traffic, traffic_src = None, None
@@ -221,7 +221,8 @@ def main():
         tdat = json.load(open(tj))
         traffic, traffic_src = tdat["gemm_bf16_avg_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
     roof = {"bound": "mfma", "kernel": {"bf16": "gemm_bf16_256x128/256x256_kernel (all bf16 MFMA GEMM launches of the step)", "fp32": "gemm_f32_kernel",
-                                        "fp8": "gemm_fp8_256x128_kernel (the e4m3 MFMA GEMM launches: QKV, MLP-in, SwiGLU MLP-out)"}[a.precision],
+                                        "fp8": "gemm_fp8_256x128_kernel (the e4m3 MFMA GEMM launches: QKV, MLP-in, SwiGLU MLP-out)",
+                                        "bf16x3": "bf16 MFMA GEMM launches on split operands (K' = 3K; achieved = ALGORITHMIC 2MNK FLOPs / time)"}[a.precision],
             "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": d["launches"] // nprof, "avg_launch_us": 1e3 * d["ms"] / max(1, d["launches"]),

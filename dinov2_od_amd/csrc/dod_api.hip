@@ -109,9 +109,11 @@ struct ProfScope {
 };
 
 inline bool is_fp8(const dod_handle* h) { return h->cfg.precision == DOD_PREC_FP8; }
+// bf16x3: the backbone block linears run as split products on the bf16 kernels; every other choice follows the fp32 mode
+inline bool is_x3(const dod_handle* h) { return h->cfg.precision == DOD_PREC_BF16X3; }
 // operand dtype of everything that is not an fp8 GEMM: bf16 in both the bf16 and the fp8 mode
 inline bool is_bf16(const dod_handle* h) { return h->cfg.precision == DOD_PREC_BF16 || is_fp8(h); }
-inline size_t esz(const dod_handle* h) { return is_bf16(h) ? 2 : 4; }
+inline size_t esz(const dod_handle* h) { return is_x3(h) ? 6 : (is_bf16(h) ? 2 : 4); }   // x3: [hi | hi | lo] bf16 per element
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 void spatial_factor(int hw, int* h, int* w) {   // deformable_attention.py:241-256
@@ -176,7 +178,7 @@ struct Packer {
   }
   // bf16x3 split weight [rows, 3*cols] (bf16 mode, cols % 64 == 0), else nullptr
   bf16_t* split_w(const float* src, int rows, int cols) {
-    if (!src || !is_bf16(h) || cols % 64) return nullptr;
+    if (!src || !(is_bf16(h) || is_x3(h)) || cols % 64) return nullptr;
     bf16_t* b = alloc<bf16_t>((size_t)rows * 3 * cols); if (!b) return nullptr;
     if (launch_split3(src, cols, b, rows, cols, 1, s)) { if (!rc) rc = fail(h, DOD_ERR_HIP, "split3 launch failed"); return nullptr; }
     return b;
@@ -249,19 +251,19 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
       HIPCHK(h, hipMemcpyAsync(L.bqkv + (size_t)t * D, b, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
     }
     if (P.rc) break;
-    const bool f8 = is_fp8(h);
-    L.Wqkv = f8 ? P.pack_fp8(cat, 3 * D, D, &L.sqkv) : P.pack_operand(cat, 3 * D, D, D);
-    L.Wo = P.pack_operand(P.eff_weight(lp + "attention.output.dense", D, D), D, D, D);
+    const bool f8 = is_fp8(h), x3 = is_x3(h);
+    L.Wqkv = x3 ? P.split_w(cat, 3 * D, D) : f8 ? P.pack_fp8(cat, 3 * D, D, &L.sqkv) : P.pack_operand(cat, 3 * D, D, D);
+    L.Wo = x3 ? P.split_w(P.eff_weight(lp + "attention.output.dense", D, D), D, D) : P.pack_operand(P.eff_weight(lp + "attention.output.dense", D, D), D, D, D);
     L.bo = P.eff_bias(lp + "attention.output.dense", D);
     if (c.swiglu) {
-      L.W1 = f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, D);
+      L.W1 = x3 ? P.split_w(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, D);
       L.b1 = P.eff_bias(lp + "mlp.weights_in", 2 * F);
-      L.W2 = f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, &L.s2) : P.pack_operand(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, F);
+      L.W2 = x3 ? P.split_w(P.eff_weight(lp + "mlp.weights_out", D, F), D, F) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, &L.s2) : P.pack_operand(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, F);
       L.b2 = P.eff_bias(lp + "mlp.weights_out", D);
     } else {
-      L.W1 = f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.fc1", F, D), F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.fc1", F, D), F, D, D);
+      L.W1 = x3 ? P.split_w(P.eff_weight(lp + "mlp.fc1", F, D), F, D) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.fc1", F, D), F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.fc1", F, D), F, D, D);
       L.b1 = P.eff_bias(lp + "mlp.fc1", F);
-      L.W2 = P.pack_operand(P.eff_weight(lp + "mlp.fc2", D, F), D, F, F);
+      L.W2 = x3 ? P.split_w(P.eff_weight(lp + "mlp.fc2", D, F), D, F) : P.pack_operand(P.eff_weight(lp + "mlp.fc2", D, F), D, F, F);
       L.b2 = P.eff_bias(lp + "mlp.fc2", D);
     }
   }
@@ -269,7 +271,7 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
   h->lnfw = P.copy(bb + "layernorm.weight", {D}); h->lnfb = P.copy(bb + "layernorm.bias", {D});
   if (c.target_dim) {
     const WRef* W = P.need("backbone.projection.weight", {c.target_dim, D});
-    if (W) h->Wproj = P.pack_operand(W->ptr, c.target_dim, D, D);
+    if (W) h->Wproj = is_x3(h) ? (void*)P.split_w(W->ptr, c.target_dim, D) : P.pack_operand(W->ptr, c.target_dim, D, D);
     h->bproj = P.copy("backbone.projection.bias", {c.target_dim});
   }
 decoder_part:
@@ -422,6 +424,13 @@ int linear(dod_handle* h, bool bf, const void* A, int lda, const void* W, int ld
   if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "linear launch rejected (M=%d N=%d K=%d bf16=%d rc=%d)", M, N, K, (int)bf, r);
   return 0;
 }
+// bf16x3 linear: A3 [M, 3K] = [Ah | Ah | Al], W3 [N, 3K] = [Wh | Wl | Wh] -> one bf16 GEMM with K' = 3K (algorithmic FLOPs reported)
+int linear3(dod_handle* h, const void* A3, const void* W3, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+  ProfScope ps(h, s, PC_GEMM_BF16, 2.0 * M * N * (double)K);
+  int r = launch_gemm_bf16((const bf16_t*)A3, 3 * K, (const bf16_t*)W3, 3 * K, M, N, 3 * K, e, s);
+  if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "bf16x3 linear launch rejected (M=%d N=%d K=%d rc=%d)", M, N, K, r);
+  return 0;
+}
 // fp8 linear: A_q [M,K] e4m3 with per-row scales, W_q [N,K] e4m3 with per-row (output feature) scales
 int linear8(dod_handle* h, const void* A, const float* a_scale, const void* W, const float* w_scale, int M, int N, int K, GemmEpi e, hipStream_t s) {
   ProfScope ps(h, s, PC_GEMM_FP8, 2.0 * M * N * (double)K);
@@ -457,8 +466,37 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   const float scale = 1.0f / std::sqrt((float)(D / g.heads));
   float* yf = bf ? nullptr : (float*)ws.y; bf16_t* yb = bf ? (bf16_t*)ws.y : nullptr;
   const bool f8 = is_fp8(h);   // LayerNorm / SwiGLU emit e4m3 rows + per-row scales (ws.rs) for the QKV / MLP linears
+  const bool x3 = is_x3(h);
   for (int i = 0; i < g.layers; ++i) {
     const BLayer& L = h->L[i];
+    if (x3) {   // bf16x3: every block linear as a split product on the bf16 kernels; attention and LayerNorm in fp32
+      bf16_t* y3 = (bf16_t*)ws.y;
+      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3)); }
+      rc = linear3(h, y3, L.Wqkv, M, 3 * D, D, epi(L.bqkv, (float*)ws.qkv, nullptr, 3 * D), s); if (rc) return rc;
+      float* ctxf = (float*)ws.hbuf;   // fp32 context, then split into ws.ctx
+      {
+        ProfScope ps(h, s, PC_ATTN_F32, 4.0 * B * (double)N * N * D);
+        AttnF32 a; const float* q = (const float*)ws.qkv;
+        a.q = q; a.k = q + D; a.v = q + 2 * D; a.o = ctxf; a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
+        a.Lq = a.Lk = N; a.B = B; a.heads = g.heads; a.dh = D / g.heads; a.scale = scale;
+        KCHK(h, launch_attn_f32(a, s));
+      }
+      KCHK(h, launch_split3(ctxf, D, (bf16_t*)ws.ctx, M, D, 0, s));
+      rc = linear3(h, ws.ctx, L.Wo, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;
+      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3)); }
+      if (g.swiglu) {
+        rc = linear3(h, y3, L.W1, M, 2 * F, D, epi(L.b1, (float*)ws.hbuf, nullptr, 2 * F), s); if (rc) return rc;
+        KCHK(h, launch_swiglu((const float*)ws.hbuf, nullptr, M, F, (float*)ws.gated, nullptr, s));
+        KCHK(h, launch_split3((const float*)ws.gated, F, (bf16_t*)ws.hbuf, M, F, 0, s));
+      } else {
+        GemmEpi e1 = epi(L.b1, nullptr, ws.hbuf, 3 * F, ACT_GELU);
+        e1.out_split = F;
+        rc = linear3(h, y3, L.W1, M, F, D, e1, s); if (rc) return rc;
+      }
+      rc = linear3(h, ws.hbuf, L.W2, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
+      tap(h, 1 + i, ws.x, false, (size_t)M * D, s);
+      continue;
+    }
     if (f8) {
       { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, nullptr, nullptr, s, (unsigned char*)ws.y, ws.rs)); }
       rc = linear8(h, ws.y, ws.rs, L.Wqkv, L.sqkv, M, 3 * D, D, epi(L.bqkv, nullptr, ws.qkv, 3 * D), s); if (rc) return rc;
@@ -507,6 +545,13 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
     if (!bf && want_mem && feat_f32) HIPCHK(h, hipMemcpyAsync(ws.mem, feat_f32, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
   } else {
     const int Dd = g.target_dim;
+    if (x3) {
+      KCHK(h, launch_layernorm(ws.x, nullptr, h->lnfw, h->lnfb, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, (bf16_t*)ws.y));
+      float* dst = feat_f32 ? feat_f32 : (float*)ws.mem;
+      rc = linear3(h, ws.y, h->Wproj, M, Dd, D, epi(h->bproj, dst, nullptr, Dd), s); if (rc) return rc;
+      if (feat_f32 && want_mem) HIPCHK(h, hipMemcpyAsync(ws.mem, feat_f32, (size_t)M * Dd * 4, hipMemcpyDeviceToDevice, s));
+      return DOD_OK;
+    }
     KCHK(h, launch_layernorm(ws.x, nullptr, h->lnfw, h->lnfb, g.ln_eps, M, D, yf, yb, s));
     if (feat_f32) { rc = linear(h, bf, ws.y, D, h->Wproj, D, M, Dd, D, epi(h->bproj, feat_f32, nullptr, Dd), s); if (rc) return rc; }
     if (want_mem) { rc = linear(h, bf, ws.y, D, h->Wproj, D, M, Dd, D, epi(h->bproj, bf ? nullptr : (float*)ws.mem, bf ? ws.mem : nullptr, Dd), s); if (rc) return rc; }
@@ -645,7 +690,10 @@ int dod_create(const dod_config* cfg, dod_handle** out) {
   const dod_config& c = *cfg;
   if (c.hidden <= 0 || c.layers <= 0 || c.heads <= 0 || c.hidden % c.heads) return fail(nullptr, DOD_ERR_INVALID, "bad backbone dims hidden=%d heads=%d layers=%d", c.hidden, c.heads, c.layers);
   if (c.hidden % 64) return fail(nullptr, DOD_ERR_INVALID, "hidden (%d) must be a multiple of 64", c.hidden);
-  if (c.ffn_hidden <= 0 || c.ffn_hidden % (c.precision != DOD_PREC_FP32 ? 64 : 4)) return fail(nullptr, DOD_ERR_INVALID, "ffn_hidden (%d) must be a multiple of %d in this precision", c.ffn_hidden, c.precision != DOD_PREC_FP32 ? 64 : 4);
+  {
+    const int fm = c.precision == DOD_PREC_FP32 ? 4 : 64;
+    if (c.ffn_hidden <= 0 || c.ffn_hidden % fm) return fail(nullptr, DOD_ERR_INVALID, "ffn_hidden (%d) must be a multiple of %d in this precision", c.ffn_hidden, fm);
+  }
   if (c.patch <= 0 || c.pos_grid <= 0) return fail(nullptr, DOD_ERR_INVALID, "bad patch/pos_grid");
   if (c.num_queries <= 0 || c.dec_hidden <= 0 || c.dec_heads <= 0 || c.dec_layers <= 0 || c.num_classes <= 0 || c.dim_feedforward <= 0) return fail(nullptr, DOD_ERR_INVALID, "bad decoder dims");
   if (c.dec_hidden % 64 || c.dim_feedforward % 4) return fail(nullptr, DOD_ERR_INVALID, "decoder hidden (%d) must be a multiple of 64, dim_feedforward (%d) of 4", c.dec_hidden, c.dim_feedforward);
@@ -653,7 +701,7 @@ int dod_create(const dod_config* cfg, dod_handle** out) {
   if (!c.target_dim && c.hidden != c.dec_hidden) return fail(nullptr, DOD_ERR_INVALID, "backbone width %d != decoder hidden %d and no projection", c.hidden, c.dec_hidden);
   if (c.use_deformable && (c.n_points <= 0 || c.n_points > 8)) return fail(nullptr, DOD_ERR_INVALID, "n_points must be 1..8");
   if (c.dec_layers > 64) return fail(nullptr, DOD_ERR_INVALID, "at most 64 decoder layers");
-  if (c.precision != DOD_PREC_FP32 && c.precision != DOD_PREC_BF16 && c.precision != DOD_PREC_FP8) return fail(nullptr, DOD_ERR_INVALID, "unknown precision %d", c.precision);
+  if (c.precision != DOD_PREC_FP32 && c.precision != DOD_PREC_BF16 && c.precision != DOD_PREC_FP8 && c.precision != DOD_PREC_BF16X3) return fail(nullptr, DOD_ERR_INVALID, "unknown precision %d", c.precision);
   dod_handle* h = new (std::nothrow) dod_handle();
   if (!h) return fail(nullptr, DOD_ERR_STATE, "out of host memory");
   h->cfg = c;

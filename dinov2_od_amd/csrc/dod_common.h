@@ -78,6 +78,7 @@ struct GemmEpi {
   const float* pos;       // [out_rows_per_img, N] (patch-embed only)
   int rows_per_img;
   int out_rows_per_img;
+  int out_split;          // > 0 with out_bf16: bf16x3 activation layout [hi | hi | lo], each out_split columns wide (ldc = 3*out_split)
   const float* a_scale;   // fp8 GEMM only: per-row (token) dequant scale of A, [M]; null otherwise
   const float* w_scale;   // fp8 GEMM only: per-output-feature dequant scale of W, [N]
 };
@@ -99,10 +100,11 @@ int launch_quant_rows_fp8(const void* x, int in_bf16, int ld, int rows, int cols
                           hipStream_t s);
 
 // rows x D LayerNorm, optional pre-add (y = LN(x + add)), fp32 statistics; out bf16 or fp32
-// out_fp8 / out_scale (both or neither): e4m3 row + per-row scale (amax / 448) instead of the fp32 / bf16 output
+// out_fp8 / out_scale (both or neither): e4m3 row + per-row scale (amax / 448) instead of the fp32 / bf16 output;
+// out_split3: bf16x3 activation layout [hi | hi | lo] (row pitch 3*D) instead
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s,
-                     unsigned char* out_fp8 = nullptr, float* out_scale = nullptr);
+                     unsigned char* out_fp8 = nullptr, float* out_scale = nullptr, bf16_t* out_split3 = nullptr);
 
 // backbone attention, bf16 MFMA flash kernel, head_dim 64.  qkv [B*N, 3*D] bf16 -> ctx [B*N, D] bf16
 int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s);

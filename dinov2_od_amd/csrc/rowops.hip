@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, int rows, int D, float* __restrict__ out_f32,
                                                         bf16_t* __restrict__ out_bf16, unsigned char* __restrict__ out_fp8,
-                                                        float* __restrict__ out_scale) {
+                                                        float* __restrict__ out_scale, bf16_t* __restrict__ out_split3) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -80,6 +80,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
       if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[c] = o;
+      if (out_split3) {   // bf16x3 operand [hi | hi | lo]
+        uint2 hi, lo;
+        hi.x = pack2bf(o.x, o.y);
+        hi.y = pack2bf(o.z, o.w);
+        lo.x = pack2bf(o.x - __uint_as_float(hi.x << 16), o.y - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = pack2bf(o.z - __uint_as_float(hi.y << 16), o.w - __uint_as_float(hi.y & 0xffff0000u));
+        bf16_t* ob = out_split3 + (size_t)row * 3 * D;
+        reinterpret_cast<uint2*>(ob)[c] = hi;
+        reinterpret_cast<uint2*>(ob + D)[c] = hi;
+        reinterpret_cast<uint2*>(ob + 2 * (size_t)D)[c] = lo;
+      }
       if (out_bf16) {
         uint2 p;
         p.x = pack2bf(o.x, o.y);
@@ -92,12 +103,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s, unsigned char* out_fp8,
-                     float* out_scale) {
+                     float* out_scale, bf16_t* out_split3) {
   if (rows <= 0) return 1;
   if (D % 4 != 0 || D > 256 * LN_MAXC) return 2;
   if ((out_fp8 == nullptr) != (out_scale == nullptr)) return 2;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, add, gamma, beta, eps, rows, D,
-                     out_f32, out_bf16, out_fp8, out_scale);
+                     out_f32, out_bf16, out_fp8, out_scale, out_split3);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -44,6 +44,9 @@ enum dod_precision {
   DOD_PREC_FP32 = 0,        /* exact-fp32 MFMA/VALU everywhere: the mode gated at 1e-3 parity  */
   DOD_PREC_BF16 = 1,        /* bf16 MFMA operands in the backbone + value projection, fp32
                                accumulate / residual stream / LayerNorm / softmax / decoder     */
+  DOD_PREC_BF16X3 = 3,      /* backbone linears as bf16x3 split products on the bf16 MFMA kernels (A = Ah + Al, W = Wh + Wl,
+                               Ah Wh + Ah Wl + Al Wh: ~1e-5 relative, fp32-class accuracy at a third of the bf16 rate);
+                               everything else as FP32.  A parity-gated mode that runs on the bf16 matrix cores   */
   DOD_PREC_FP8 = 2          /* as BF16, with the QKV / MLP-in (/ SwiGLU MLP-out) linears on OCP e4m3 MFMA operands:
                                per-token activation scales from the producing LayerNorm / SwiGLU kernel, per-output-
                                feature weight scales (BASELINE configs[4]: ViT-g/14 fp8)          */

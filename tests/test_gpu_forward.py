@@ -39,14 +39,21 @@ def _taps(m, B, N, bb, dc):
     return t
 
 
+# parity-gated modes: "fp32" (exact-fp32 MFMA / VALU) and "bf16x3" (split products on the bf16 MFMA kernels, ~1e-5)
+GATED = ["fp32", "bf16x3"]
+
+
+@pytest.mark.parametrize("precision", GATED)
 @pytest.mark.parametrize("swiglu", [False, True])
 @pytest.mark.parametrize("R", [70, 56])
-def test_strict_micro_backbone_every_stage_vs_reference(G, swiglu, R):
+def test_strict_micro_backbone_every_stage_vs_reference(G, swiglu, R, precision):
     """G0/G4 goldens: embeddings (incl. bicubic 5->4 at 56x56), each block, final features."""
     from dinov2_od_amd.models import DINOv2Backbone
+    if swiglu and precision == "bf16x3":
+        pytest.skip("the micro SwiGLU width (344) is not a multiple of 64: bf16 MFMA K-tiles need that")
     g = cases.golden("g4_micro_swiglu" if swiglu else "g0_micro_backbone")
     bb = cases.micro_bb(swiglu)
-    m = DINOv2Backbone("micro", lora_r=2, lora_alpha=1.0, target_dim=None, pretrained=False, precision="fp32", config=bb)
+    m = DINOv2Backbone("micro", lora_r=2, lora_alpha=1.0, target_dim=None, pretrained=False, precision=precision, config=bb)
     G.load_np_state(m, synth.backbone_state_dict(bb, seed=1, prefix=""))
     m = m.to(G.dev()).eval()
     x = G.to_gpu(synth.make_pixels(2, R, R, seed=0))
@@ -56,10 +63,11 @@ def test_strict_micro_backbone_every_stage_vs_reference(G, swiglu, R):
     blocks = [eng.set_tap(1 + i, (2, N, bb.hidden), "cuda:0") for i in range(bb.layers)]
     f = m(x)
     G.sync()
+    stage_tol = 1e-5 if precision == "fp32" else 5e-5      # bf16x3 drops the lo*lo products (2^-18 relative)
     assert rel_err(emb.cpu().numpy(), g[f"embeddings_{R}"]) < 1e-5
     for i, b in enumerate(blocks):
-        assert rel_err(b.cpu().numpy(), g[f"block{i}_{R}"]) < 1e-5, i
-    assert rel_err(f.cpu().numpy(), g[f"features_{R}"]) < 1e-5
+        assert rel_err(b.cpu().numpy(), g[f"block{i}_{R}"]) < stage_tol, i
+    assert rel_err(f.cpu().numpy(), g[f"features_{R}"]) < stage_tol
 
 
 @pytest.mark.parametrize("case", cases.G1_CASES, ids=[c[0] for c in cases.G1_CASES])
@@ -84,12 +92,13 @@ def test_decoder_only_vs_reference(G, case, precision):
         assert rel_err(out["pred_boxes"].cpu().numpy(), g[f"{tag}_N{N}_boxes"]) < tol, (tag, N)
 
 
+@pytest.mark.parametrize("precision", GATED)
 @pytest.mark.parametrize("Q", [25, 100])
-def test_strict_cfg1_end_to_end_vs_reference(G, Q):
+def test_strict_cfg1_end_to_end_vs_reference(G, Q, precision):
     """BASELINE.json configs[0]: --lightweight ViT-S/14 224x224, batch 2."""
     g = cases.golden(f"g2_cfg1_q{Q}")
     bb, dc = cases.cfg1(Q)
-    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-small")
+    m = G.make_detector(bb, dc, precision, "facebook/dinov2-small")
     out = m(G.to_gpu(synth.make_pixels(2, 224, 224, seed=0)))
     G.sync()
     assert out["pred_logits"].shape == (2, Q, 91) and out["pred_boxes"].shape == (2, Q, 4)
@@ -97,12 +106,13 @@ def test_strict_cfg1_end_to_end_vs_reference(G, Q):
     assert rel_err(out["pred_boxes"].cpu().numpy(), g["pred_boxes"]) < TOL
 
 
+@pytest.mark.parametrize("precision", GATED)
 @pytest.mark.parametrize("name,R,deform", [("g3_vitb_224", 224, True), ("g3_vitb_518", 518, True), ("g3_vitb_224_dense", 224, False)])
-def test_strict_vitb_end_to_end_vs_reference(G, name, R, deform):
+def test_strict_vitb_end_to_end_vs_reference(G, name, R, deform, precision):
     """ViT-B/14 at 224 (bicubic pos resize, (h,w)=(1,257)) and 518 (N=1370, (10,137)); Q=100."""
     g = cases.golden(name)
     bb, dc = cases.vitb(100, deform)
-    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-base")
+    m = G.make_detector(bb, dc, precision, "facebook/dinov2-base")
     x = synth.make_pixels(1, R, R, seed=0)
     N = num_tokens(R, R)
     eng = m._get_engine()
