@@ -243,29 +243,38 @@ def main():
             det_now = model.forward_packed(x[:2]).clone()
             torch.cuda.synchronize()
         res["cpu_baseline"], oracle_first = cpu_baseline(bb, dc, R, gpu_det=det_now)
-        res["precision_note"] = ("bf16 MFMA operands cannot meet the 1e-3 gate on logits (DESIGN.md section 2); the fp32 mode does "
-                                 "and is the mode the parity tests gate")
+        res["precision_note"] = ("single-pass bf16 MFMA operands (the configuration BASELINE names) cannot meet the 1e-3 gate on logits "
+                                 "(8-bit mantissa; DESIGN.md section 2): see gpu_vs_oracle.  The parity-gated modes -- bf16x3 "
+                                 "(split products on the same bf16 MFMA kernels) and fp32 -- do, and are measured below on the same workload")
         if a.precision == "bf16":
-            # throughput of the parity-gated mode, for reference (small sample: 2 steps of 8 images)
-            try:
-                del model
-                torch.cuda.empty_cache()
-                m32, _, _ = build(name, Q, "fp32", device)
-                xs = x[:8].contiguous()
+            def gated(prec, nb, steps):
+                m2, _, _ = build(name, Q, prec, device)
+                xs = x[:nb].contiguous()
                 with torch.no_grad():
-                    d32 = m32.forward_packed(xs).clone()
+                    d2 = m2.forward_packed(xs).clone()
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    for _ in range(2):
-                        m32.forward_packed(xs)
+                    for _ in range(steps):
+                        m2.forward_packed(xs)
                     torch.cuda.synchronize()
-                    t32 = (time.perf_counter() - t1) / 2
-                res["fp32_mode"] = {"value": xs.shape[0] / t32, "unit": "images/s", "batch": int(xs.shape[0]),
-                                    "gpu_vs_oracle": oracle_error(d32, oracle_first, dc.num_classes),
-                                    "note": "exact-fp32 MFMA / VALU path, the mode gated at 1e-3 against the reference "
-                                            "(tests/test_gpu_forward.py)"}
-            except Exception as e:
-                res["fp32_mode"] = {"error": f"{type(e).__name__}: {e}"}
+                    t2 = (time.perf_counter() - t1) / steps
+                out = {"precision": prec, "value": nb / t2, "unit": "images/s", "batch": nb, "ms_per_step": 1e3 * t2,
+                       "gpu_vs_oracle": oracle_error(d2, oracle_first, dc.num_classes),
+                       "mfma_roofline_frac_end_to_end_algorithmic": nb / t2 * fpi / PEAK_BF16}
+                del m2
+                torch.cuda.empty_cache()
+                return out
+            del model
+            torch.cuda.empty_cache()
+            for key, prec, nb, steps in (("parity_gated_mode", "bf16x3", B_local, 5), ("fp32_mode", "fp32", min(8, B_local), 2)):
+                try:
+                    res[key] = gated(prec, nb, steps)
+                except Exception as e:
+                    res[key] = {"error": f"{type(e).__name__}: {e}"}
+            if "value" in res.get("parity_gated_mode", {}):
+                res["parity_gated_mode"]["note"] = ("every backbone product as bf16 split products (Ah Wh + Ah Wl + Al Wh) on the bf16 MFMA "
+                                                    "kernels incl. the flash attention, fp32 elsewhere: within 1e-3 of the reference "
+                                                    "(tests/test_gpu_forward.py GATED); 3x the MFMA work of the single-pass bf16 mode")
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

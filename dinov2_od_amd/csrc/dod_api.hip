@@ -472,16 +472,24 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
     if (x3) {   // bf16x3: every block linear as a split product on the bf16 kernels; attention and LayerNorm in fp32
       bf16_t* y3 = (bf16_t*)ws.y;
       { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3)); }
-      rc = linear3(h, y3, L.Wqkv, M, 3 * D, D, epi(L.bqkv, (float*)ws.qkv, nullptr, 3 * D), s); if (rc) return rc;
-      float* ctxf = (float*)ws.hbuf;   // fp32 context, then split into ws.ctx
-      {
-        ProfScope ps(h, s, PC_ATTN_F32, 4.0 * B * (double)N * N * D);
-        AttnF32 a; const float* q = (const float*)ws.qkv;
-        a.q = q; a.k = q + D; a.v = q + 2 * D; a.o = ctxf; a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
-        a.Lq = a.Lk = N; a.B = B; a.heads = g.heads; a.dh = D / g.heads; a.scale = scale;
-        KCHK(h, launch_attn_f32(a, s));
+      if (D / g.heads == 64) {   // split-product flash attention on the bf16 MFMA cores
+        GemmEpi eq = epi(L.bqkv, nullptr, ws.qkv, 6 * D);
+        eq.out_split = -3 * D;       // [hi(q|k|v) | lo(q|k|v)]
+        rc = linear3(h, y3, L.Wqkv, M, 3 * D, D, eq, s); if (rc) return rc;
+        ProfScope ps(h, s, PC_ATTN_BF16, 4.0 * B * (double)N * N * D);
+        KCHK(h, launch_attn_x3((const bf16_t*)ws.qkv, (bf16_t*)ws.ctx, B, N, g.heads, scale, s));
+      } else {                    // other head sizes (micro test models): generic fp32 attention, then split
+        rc = linear3(h, y3, L.Wqkv, M, 3 * D, D, epi(L.bqkv, (float*)ws.qkv, nullptr, 3 * D), s); if (rc) return rc;
+        float* ctxf = (float*)ws.hbuf;
+        {
+          ProfScope ps(h, s, PC_ATTN_F32, 4.0 * B * (double)N * N * D);
+          AttnF32 a; const float* q = (const float*)ws.qkv;
+          a.q = q; a.k = q + D; a.v = q + 2 * D; a.o = ctxf; a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
+          a.Lq = a.Lk = N; a.B = B; a.heads = g.heads; a.dh = D / g.heads; a.scale = scale;
+          KCHK(h, launch_attn_f32(a, s));
+        }
+        KCHK(h, launch_split3(ctxf, D, (bf16_t*)ws.ctx, M, D, 0, s));
       }
-      KCHK(h, launch_split3(ctxf, D, (bf16_t*)ws.ctx, M, D, 0, s));
       rc = linear3(h, ws.ctx, L.Wo, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;
       { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3)); }
       if (g.swiglu) {

@@ -78,7 +78,8 @@ struct GemmEpi {
   const float* pos;       // [out_rows_per_img, N] (patch-embed only)
   int rows_per_img;
   int out_rows_per_img;
-  int out_split;          // > 0 with out_bf16: bf16x3 activation layout [hi | hi | lo], each out_split columns wide (ldc = 3*out_split)
+  int out_split;          // with out_bf16: > 0 bf16x3 activation layout [hi | hi | lo], each out_split columns wide (ldc = 3*out_split);
+                          // < 0 pair layout [hi | lo], each -out_split wide (ldc = -2*out_split)
   const float* a_scale;   // fp8 GEMM only: per-row (token) dequant scale of A, [M]; null otherwise
   const float* w_scale;   // fp8 GEMM only: per-output-feature dequant scale of W, [N]
 };
@@ -94,6 +95,8 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
                     const GemmEpi& e, hipStream_t s);
 // rows x cols fp32 or bf16 -> e4m3 with one scale per row: scale[r] = amax_r / 448 (1 if the row is all zero),
 // q = rne_e4m3(x / scale[r]).  in_bf16: input element type.  ld in elements.
+// bf16x3-mode attention: qkv2 [B*N, 6*D] = [hi(q|k|v) | lo(q|k|v)] -> ctx3 [B*N, 3*D] = [hi | hi | lo]; head_dim 64
+int launch_attn_x3(const bf16_t* qkv2, bf16_t* ctx3, int B, int N, int heads, float scale, hipStream_t s);
 // SwiGLU (silu(a) * b of the bf16 [rows, 2*Fh] input) -> e4m3 [rows, Fh] + per-row scale
 int launch_swiglu_fp8(const bf16_t* in, int rows, int Fh, unsigned char* q, float* scale, hipStream_t s);
 int launch_quant_rows_fp8(const void* x, int in_bf16, int ld, int rows, int cols, unsigned char* q, int ldq, float* scale,

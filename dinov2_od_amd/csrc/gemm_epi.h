@@ -80,6 +80,15 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
       *reinterpret_cast<uint2*>(o) = hi;
       *reinterpret_cast<uint2*>(o + e.out_split) = hi;
       *reinterpret_cast<uint2*>(o + 2 * (size_t)e.out_split) = lo;
+    } else if (e.out_split < 0) {   // pair layout [hi | lo] (attention input of the bf16x3 mode)
+      uint2 hi, lo;
+      hi.x = pack2bf(v.x, v.y);
+      hi.y = pack2bf(v.z, v.w);
+      lo.x = pack2bf(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
+      lo.y = pack2bf(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
+      bf16_t* o = e.out_bf16 + orow * e.ldc + n;
+      *reinterpret_cast<uint2*>(o) = hi;
+      *reinterpret_cast<uint2*>(o - e.out_split) = lo;
     } else {
       uint2 o;
       o.x = pack2bf(v.x, v.y);
