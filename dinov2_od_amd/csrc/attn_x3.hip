@@ -5,7 +5,7 @@
 //   S^T = K Q^T  as  Kh Qh^T + Kh Ql^T + Kl Qh^T          (24 MFMAs per 64-key tile and 32-query block)
 //   O^T += V^T P^T  as  Vh^T Ph^T + Vh^T Pl^T + Vl^T Ph^T  (24 MFMAs), P split in registers after the fp32 softmax
 // Input: the QKV linear's epilogue writes the pair layout [hi(q|k|v) | lo(q|k|v)] (row pitch 6*D bf16);
-// output: the context in the [hi | hi | lo] activation layout of the next split GEMM (row pitch 3*D).
+// output: the context in the same pair layout [hi | lo] (row pitch 2*D), the A operand of the split out-proj GEMM.
 // Structure as attn_bf16.hip with one 32-query block per wave: workgroup = 4 waves = 128 query rows of one (image, head);
 // K/V tiles of 64 keys (four planes: Kh, Kl, Vh, Vl = 32 KiB) stream by LDS-DMA into TWO slots (64 KiB, two workgroups
 // per CU): tile t+1 is in flight while tile t is computed; same swizzles, query-on-lane products, tr-reads for V^T.
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const bf16_t* __restric
   const float inv = 1.0f / l_tot;
   const int q = q0 + lr;
   if (active && q < N) {
-    bf16_t* op = ctx3 + ((size_t)b * N + q) * 3 * D + h * 64;
+    bf16_t* op = ctx3 + ((size_t)b * N + q) * 2 * D + h * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -231,13 +231,12 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const bf16_t* __restric
         lo.y = pack2bf(v2 - __uint_as_float(hi.y << 16), v3 - __uint_as_float(hi.y & 0xffff0000u));
         bf16_t* p = op + db * 32 + 8 * g + 4 * lh;
         *reinterpret_cast<uint2*>(p) = hi;
-        *reinterpret_cast<uint2*>(p + D) = hi;
-        *reinterpret_cast<uint2*>(p + 2 * (size_t)D) = lo;
+        *reinterpret_cast<uint2*>(p + D) = lo;
       }
   }
 }
 
-// qkv2 [B*N, 6*D] bf16 = [hi(q|k|v) | lo(q|k|v)]  ->  ctx3 [B*N, 3*D] bf16 = [hi | hi | lo]
+// qkv2 [B*N, 6*D] bf16 = [hi(q|k|v) | lo(q|k|v)]  ->  ctx3 [B*N, 2*D] bf16 = [hi | lo]
 int launch_attn_x3(const bf16_t* qkv2, bf16_t* ctx3, int B, int N, int heads, float scale, hipStream_t s) {
   if (B <= 0 || N <= 0 || heads <= 0) return 1;
   const int npairs = B * heads, pairs8 = (npairs + 7) / 8 * 8;

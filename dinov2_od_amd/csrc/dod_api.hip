@@ -183,6 +183,13 @@ struct Packer {
     if (launch_split3(src, cols, b, rows, cols, 1, s)) { if (!rc) rc = fail(h, DOD_ERR_HIP, "split3 launch failed"); return nullptr; }
     return b;
   }
+  // split-product weight in the pair layout [Wh | Wl] (bf16x3 mode, gemm_x3.hip)
+  bf16_t* pair_w(const float* src, int rows, int cols) {
+    if (!src || cols % 32) return nullptr;
+    bf16_t* b = alloc<bf16_t>((size_t)rows * 2 * cols); if (!b) return nullptr;
+    if (launch_split2(src, cols, b, rows, cols, s)) { if (!rc) rc = fail(h, DOD_ERR_HIP, "split2 launch failed"); return nullptr; }
+    return b;
+  }
   // fp32 [rows, cols] -> e4m3 rows + per-row (output feature) scales
   void* pack_fp8(const float* src, int rows, int cols, float** scale_out) {
     if (!src) return nullptr;
@@ -252,18 +259,18 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
     }
     if (P.rc) break;
     const bool f8 = is_fp8(h), x3 = is_x3(h);
-    L.Wqkv = x3 ? P.split_w(cat, 3 * D, D) : f8 ? P.pack_fp8(cat, 3 * D, D, &L.sqkv) : P.pack_operand(cat, 3 * D, D, D);
-    L.Wo = x3 ? P.split_w(P.eff_weight(lp + "attention.output.dense", D, D), D, D) : P.pack_operand(P.eff_weight(lp + "attention.output.dense", D, D), D, D, D);
+    L.Wqkv = x3 ? P.pair_w(cat, 3 * D, D) : f8 ? P.pack_fp8(cat, 3 * D, D, &L.sqkv) : P.pack_operand(cat, 3 * D, D, D);
+    L.Wo = x3 ? P.pair_w(P.eff_weight(lp + "attention.output.dense", D, D), D, D) : P.pack_operand(P.eff_weight(lp + "attention.output.dense", D, D), D, D, D);
     L.bo = P.eff_bias(lp + "attention.output.dense", D);
     if (c.swiglu) {
-      L.W1 = x3 ? P.split_w(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, D);
+      L.W1 = x3 ? P.pair_w(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, D);
       L.b1 = P.eff_bias(lp + "mlp.weights_in", 2 * F);
-      L.W2 = x3 ? P.split_w(P.eff_weight(lp + "mlp.weights_out", D, F), D, F) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, &L.s2) : P.pack_operand(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, F);
+      L.W2 = x3 ? P.pair_w(P.eff_weight(lp + "mlp.weights_out", D, F), D, F) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, &L.s2) : P.pack_operand(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, F);
       L.b2 = P.eff_bias(lp + "mlp.weights_out", D);
     } else {
-      L.W1 = x3 ? P.split_w(P.eff_weight(lp + "mlp.fc1", F, D), F, D) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.fc1", F, D), F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.fc1", F, D), F, D, D);
+      L.W1 = x3 ? P.pair_w(P.eff_weight(lp + "mlp.fc1", F, D), F, D) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.fc1", F, D), F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.fc1", F, D), F, D, D);
       L.b1 = P.eff_bias(lp + "mlp.fc1", F);
-      L.W2 = x3 ? P.split_w(P.eff_weight(lp + "mlp.fc2", D, F), D, F) : P.pack_operand(P.eff_weight(lp + "mlp.fc2", D, F), D, F, F);
+      L.W2 = x3 ? P.pair_w(P.eff_weight(lp + "mlp.fc2", D, F), D, F) : P.pack_operand(P.eff_weight(lp + "mlp.fc2", D, F), D, F, F);
       L.b2 = P.eff_bias(lp + "mlp.fc2", D);
     }
   }
@@ -271,7 +278,7 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
   h->lnfw = P.copy(bb + "layernorm.weight", {D}); h->lnfb = P.copy(bb + "layernorm.bias", {D});
   if (c.target_dim) {
     const WRef* W = P.need("backbone.projection.weight", {c.target_dim, D});
-    if (W) h->Wproj = is_x3(h) ? (void*)P.split_w(W->ptr, c.target_dim, D) : P.pack_operand(W->ptr, c.target_dim, D, D);
+    if (W) h->Wproj = is_x3(h) ? (void*)P.pair_w(W->ptr, c.target_dim, D) : P.pack_operand(W->ptr, c.target_dim, D, D);
     h->bproj = P.copy("backbone.projection.bias", {c.target_dim});
   }
 decoder_part:
@@ -424,10 +431,10 @@ int linear(dod_handle* h, bool bf, const void* A, int lda, const void* W, int ld
   if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "linear launch rejected (M=%d N=%d K=%d bf16=%d rc=%d)", M, N, K, (int)bf, r);
   return 0;
 }
-// bf16x3 linear: A3 [M, 3K] = [Ah | Ah | Al], W3 [N, 3K] = [Wh | Wl | Wh] -> one bf16 GEMM with K' = 3K (algorithmic FLOPs reported)
+// bf16x3 linear on pair-layout operands A2 [M, 2K] = [Ah | Al], W2 [N, 2K] = [Wh | Wl] (gemm_x3.hip; algorithmic FLOPs reported)
 int linear3(dod_handle* h, const void* A3, const void* W3, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
   ProfScope ps(h, s, PC_GEMM_BF16, 2.0 * M * N * (double)K);
-  int r = launch_gemm_bf16((const bf16_t*)A3, 3 * K, (const bf16_t*)W3, 3 * K, M, N, 3 * K, e, s);
+  int r = launch_gemm_x3((const bf16_t*)A3, 2 * K, (const bf16_t*)W3, 2 * K, M, N, K, e, s);
   if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "bf16x3 linear launch rejected (M=%d N=%d K=%d rc=%d)", M, N, K, r);
   return 0;
 }
@@ -488,17 +495,17 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
           a.Lq = a.Lk = N; a.B = B; a.heads = g.heads; a.dh = D / g.heads; a.scale = scale;
           KCHK(h, launch_attn_f32(a, s));
         }
-        KCHK(h, launch_split3(ctxf, D, (bf16_t*)ws.ctx, M, D, 0, s));
+        KCHK(h, launch_split2(ctxf, D, (bf16_t*)ws.ctx, M, D, s));
       }
       rc = linear3(h, ws.ctx, L.Wo, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;
       { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3)); }
       if (g.swiglu) {
         rc = linear3(h, y3, L.W1, M, 2 * F, D, epi(L.b1, (float*)ws.hbuf, nullptr, 2 * F), s); if (rc) return rc;
         KCHK(h, launch_swiglu((const float*)ws.hbuf, nullptr, M, F, (float*)ws.gated, nullptr, s));
-        KCHK(h, launch_split3((const float*)ws.gated, F, (bf16_t*)ws.hbuf, M, F, 0, s));
+        KCHK(h, launch_split2((const float*)ws.gated, F, (bf16_t*)ws.hbuf, M, F, s));
       } else {
-        GemmEpi e1 = epi(L.b1, nullptr, ws.hbuf, 3 * F, ACT_GELU);
-        e1.out_split = F;
+        GemmEpi e1 = epi(L.b1, nullptr, ws.hbuf, 2 * F, ACT_GELU);
+        e1.out_split = -F;            // pair layout [hi | lo]
         rc = linear3(h, y3, L.W1, M, F, D, e1, s); if (rc) return rc;
       }
       rc = linear3(h, ws.hbuf, L.W2, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;

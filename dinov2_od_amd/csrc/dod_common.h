@@ -95,7 +95,7 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
                     const GemmEpi& e, hipStream_t s);
 // rows x cols fp32 or bf16 -> e4m3 with one scale per row: scale[r] = amax_r / 448 (1 if the row is all zero),
 // q = rne_e4m3(x / scale[r]).  in_bf16: input element type.  ld in elements.
-// bf16x3-mode attention: qkv2 [B*N, 6*D] = [hi(q|k|v) | lo(q|k|v)] -> ctx3 [B*N, 3*D] = [hi | hi | lo]; head_dim 64
+// bf16x3-mode attention: qkv2 [B*N, 6*D] = [hi(q|k|v) | lo(q|k|v)] -> ctx2 [B*N, 2*D] = [hi | lo]; head_dim 64
 int launch_attn_x3(const bf16_t* qkv2, bf16_t* ctx3, int B, int N, int heads, float scale, hipStream_t s);
 // SwiGLU (silu(a) * b of the bf16 [rows, 2*Fh] input) -> e4m3 [rows, Fh] + per-row scale
 int launch_swiglu_fp8(const bf16_t* in, int rows, int Fh, unsigned char* q, float* scale, hipStream_t s);
@@ -104,7 +104,7 @@ int launch_quant_rows_fp8(const void* x, int in_bf16, int ld, int rows, int cols
 
 // rows x D LayerNorm, optional pre-add (y = LN(x + add)), fp32 statistics; out bf16 or fp32
 // out_fp8 / out_scale (both or neither): e4m3 row + per-row scale (amax / 448) instead of the fp32 / bf16 output;
-// out_split3: bf16x3 activation layout [hi | hi | lo] (row pitch 3*D) instead
+// out_split3: split-product pair layout [hi | lo] (row pitch 2*D) instead
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s,
                      unsigned char* out_fp8 = nullptr, float* out_scale = nullptr, bf16_t* out_split3 = nullptr);
@@ -137,6 +137,9 @@ int launch_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int rows
 int launch_lora_merge(const float* W, const float* A, const float* Bm, float alpha, int out_f, int in_f, int r, float* dst, hipStream_t s);
 // bf16x3 split: fp32 [rows,K] -> bf16 [rows,3K]; mode 0 = [hi|hi|lo] (activations), 1 = [hi|lo|hi] (weights)
 int launch_split3(const float* in, int ld_in, bf16_t* out, int rows, int K, int mode, hipStream_t s);
+int launch_split2(const float* in, int ld_in, bf16_t* out, int rows, int K, hipStream_t s);   // [hi | lo], pitch 2K
+// split-product GEMM on pair-layout operands A2 [M, 2K], W2 [N, 2K] (gemm_x3.hip)
+int launch_gemm_x3(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 // tgt[b][q][:] = query_embed[q][:]
 int launch_bcast_rows(const float* src, float* dst, int B, int rows, int D, hipStream_t s);
 

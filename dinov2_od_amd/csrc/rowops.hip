@@ -80,16 +80,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
       if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[c] = o;
-      if (out_split3) {   // bf16x3 operand [hi | hi | lo]
+      if (out_split3) {   // split-product operand in the pair layout [hi | lo] (row pitch 2*D)
         uint2 hi, lo;
         hi.x = pack2bf(o.x, o.y);
         hi.y = pack2bf(o.z, o.w);
         lo.x = pack2bf(o.x - __uint_as_float(hi.x << 16), o.y - __uint_as_float(hi.x & 0xffff0000u));
         lo.y = pack2bf(o.z - __uint_as_float(hi.y << 16), o.w - __uint_as_float(hi.y & 0xffff0000u));
-        bf16_t* ob = out_split3 + (size_t)row * 3 * D;
+        bf16_t* ob = out_split3 + (size_t)row * 2 * D;
         reinterpret_cast<uint2*>(ob)[c] = hi;
-        reinterpret_cast<uint2*>(ob + D)[c] = hi;
-        reinterpret_cast<uint2*>(ob + 2 * (size_t)D)[c] = lo;
+        reinterpret_cast<uint2*>(ob + D)[c] = lo;
       }
       if (out_bf16) {
         uint2 p;
@@ -300,6 +299,26 @@ __global__ void split3_kernel(const float* __restrict__ in, int ld_in, bf16_t* _
     o[K] = mode ? lo : hi;
     o[2 * (size_t)K] = mode ? hi : lo;
   }
+}
+// pair layout [hi | lo] (row pitch 2K): operands of the split-product kernels (gemm_x3.hip, attn_x3.hip)
+__global__ void split2_kernel(const float* __restrict__ in, int ld_in, bf16_t* __restrict__ out, int rows, int K) {
+  const size_t total = (size_t)rows * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / K;
+    const int c = (int)(i - r * K);
+    const float x = in[r * ld_in + c];
+    const bf16_t hi = f2bf(x);
+    bf16_t* o = out + r * 2 * (size_t)K + c;
+    o[0] = hi;
+    o[K] = f2bf(x - bf2f(hi));
+  }
+}
+int launch_split2(const float* in, int ld_in, bf16_t* out, int rows, int K, hipStream_t s) {
+  const size_t total = (size_t)rows * K;
+  if (total == 0) return 0;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split2_kernel, dim3(blocks), dim3(256), 0, s, in, ld_in, out, rows, K);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 int launch_split3(const float* in, int ld_in, bf16_t* out, int rows, int K, int mode, hipStream_t s) {
   const size_t total = (size_t)rows * K;
