@@ -33,6 +33,8 @@ struct DLayer {
   // deformable
   float *cat_w = nullptr, *cat_b = nullptr, *op_w = nullptr, *op_b = nullptr, *vp_b = nullptr;
   void* vp_w = nullptr;            // bf16 / fp32
+  bf16_t* vp_w2 = nullptr;         // bf16x3 mode: pair layout
+  bf16_t* ca_kv_w2 = nullptr;
   int vp_alias = -1;               // index of an earlier layer with the same (tied) value_proj, or -1
   // standard branch cross attention
   float *ca_q_w = nullptr, *ca_q_b = nullptr, *ca_kv_b = nullptr, *ca_out_w = nullptr, *ca_out_b = nullptr;
@@ -51,6 +53,7 @@ struct dod_handle {
   // packed
   std::vector<BLayer> L;
   void* Wpatch = nullptr; int Kp = 0;
+  bf16_t* Wpatch2 = nullptr; int Kp2 = 0;   // bf16x3 mode: pair-layout patch weight, K padded to a multiple of 32
   float *bpatch = nullptr, *cls = nullptr, *pos = nullptr, *lnfw = nullptr, *lnfb = nullptr, *bproj = nullptr;
   void* Wproj = nullptr;
   std::vector<DLayer> DL;
@@ -236,6 +239,11 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
     const int K = 3 * p * p;
     h->Kp = is_bf16(h) ? (K + 63) / 64 * 64 : K;
     if (W) h->Wpatch = P.pack_operand(W->ptr, D, K, h->Kp);
+    if (W && is_x3(h)) {
+      h->Kp2 = (K + 31) / 32 * 32;
+      float* padded = P.alloc<float>((size_t)D * h->Kp2, true);
+      if (padded && !launch_copy2d(W->ptr, K, padded, h->Kp2, D, K, h->Kp2, s)) h->Wpatch2 = P.pair_w(padded, D, h->Kp2);
+    }
   }
   // ---- encoder blocks
   h->L.resize(c.layers);
@@ -332,13 +340,17 @@ decoder_part:
           const std::string kp = dp + "decoder.layers." + std::to_string(k) + ".";
           if (h->w[kp + "cross_attn.value_proj.weight"].ptr == vw->ptr && h->w[kp + "cross_attn.value_proj.bias"].ptr == vb->ptr) { L.vp_alias = h->DL[k].vp_alias >= 0 ? h->DL[k].vp_alias : k; break; }
         }
-        if (L.vp_alias < 0) { L.vp_w = P.pack_operand(vw->ptr, Dd, Dd, Dd); L.vp_b = P.copy(lp + "cross_attn.value_proj.bias", {Dd}); }
+        if (L.vp_alias < 0) {
+          L.vp_w = P.pack_operand(vw->ptr, Dd, Dd, Dd); L.vp_b = P.copy(lp + "cross_attn.value_proj.bias", {Dd});
+          if (is_x3(h)) L.vp_w2 = P.pair_w(vw->ptr, Dd, Dd);
+        }
       } else {
         const WRef* iw = P.need(lp + "multihead_attn.in_proj_weight", {3 * Dd, Dd});
         const WRef* ib = P.need(lp + "multihead_attn.in_proj_bias", {3 * Dd});
         if (!iw || !ib) break;
         L.ca_q_w = (float*)P.pack_operand(iw->ptr, Dd, Dd, Dd, true);
         L.ca_kv_w = P.pack_operand(iw->ptr + (size_t)Dd * Dd, 2 * Dd, Dd, Dd);
+        if (is_x3(h)) L.ca_kv_w2 = P.pair_w(iw->ptr + (size_t)Dd * Dd, 2 * Dd, Dd);
         L.ca_q_b = P.alloc<float>(Dd); L.ca_kv_b = P.alloc<float>(2 * Dd);
         if (P.rc) break;
         HIPCHK(h, hipMemcpyAsync(L.ca_q_b, ib->ptr, (size_t)Dd * 4, hipMemcpyDeviceToDevice, s));
@@ -364,7 +376,7 @@ struct Carver {
   void* take(size_t bytes) { void* p = base ? base + off : nullptr; off += align_up(bytes); return p; }
 };
 
-struct DecWS { float *tgt, *t2, *att, *samp, *qkv, *proj, *ffn, *hb, *qd; void* mem_op; float* values; float* kv; bf16_t* a3; };
+struct DecWS { float *tgt, *t2, *att, *samp, *qkv, *proj, *ffn, *hb, *qd; void* mem_op; float* values; float* kv; bf16_t* a3; bf16_t* mem2; };   // mem2: bf16x3 mode, memory in the pair layout [M, 2*Dd]
 struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; float* rs; };   // rs: fp8 mode, per-row activation scales [M]
 
 size_t carve_decoder(const dod_handle* h, Carver& c, int B, int N, DecWS* w, bool need_mem_op) {
@@ -376,7 +388,8 @@ size_t carve_decoder(const dod_handle* h, Carver& c, int B, int N, DecWS* w, boo
   t.proj = (float*)c.take(BQ * (size_t)(h->ncat > 0 ? h->ncat : 4) * 4);
   t.ffn = (float*)c.take(BQ * (size_t)g.dim_feedforward * 4); t.hb = (float*)c.take(BQ * (Dd / 2) * 4);
   t.qd = (float*)c.take(BQ * Dd * 4);
-  { const size_t kmax = Dd > (size_t)g.dim_feedforward ? Dd : (size_t)g.dim_feedforward; t.a3 = is_bf16(h) ? (bf16_t*)c.take(BQ * 3 * kmax * 2) : nullptr; }
+  { const size_t kmax = Dd > (size_t)g.dim_feedforward ? Dd : (size_t)g.dim_feedforward; t.a3 = (is_bf16(h) || is_x3(h)) ? (bf16_t*)c.take(BQ * 3 * kmax * 2) : nullptr; }
+  t.mem2 = is_x3(h) ? (bf16_t*)c.take(M * 2 * Dd * 2) : nullptr;
   t.mem_op = need_mem_op ? c.take(M * Dd * esz(h)) : nullptr;
   if (g.use_deformable) {
     int uniq = 0; for (auto& L : h->DL) if (L.vp_alias < 0) ++uniq;
@@ -462,11 +475,22 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   if (bf && D / g.heads != 64) return fail(h, DOD_ERR_INVALID, "bf16 attention kernel needs head_dim 64 (got %d)", D / g.heads);
   int rc = prepare_impl(h, H, W, s); if (rc) return rc;
   // K1 + K2: im2col -> GEMM with bias + position add, rows remapped past the CLS slot
+  if (is_x3(h) && h->Wpatch2 && (size_t)3 * D * 6 >= (size_t)h->Kp2 * 4) {   // split-product patch embed (pair operand staged in ws.qkv)
+    const int K2 = h->Kp2;
+    KCHK(h, launch_im2col(pixels, B, H, W, p, K2, (float*)ws.hbuf, nullptr, s));
+    KCHK(h, launch_split2((const float*)ws.hbuf, K2, (bf16_t*)ws.qkv, B * Np, K2, s));
+    GemmEpi e = epi(h->bpatch, ws.x, nullptr, D);
+    e.pos = h->pos_hw; e.rows_per_img = Np; e.out_rows_per_img = N;
+    ProfScope ps(h, s, PC_GEMM_BF16, 2.0 * B * Np * (double)D * 3.0 * p * p);
+    int r = launch_gemm_x3((const bf16_t*)ws.qkv, 2 * K2, h->Wpatch2, 2 * K2, B * Np, D, K2, e, s);
+    if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "split patch-embed GEMM rejected (rc %d)", r);
+  } else {
   KCHK(h, launch_im2col(pixels, B, H, W, p, h->Kp, bf ? nullptr : (float*)ws.hbuf, bf ? (bf16_t*)ws.hbuf : nullptr, s));
   {
     GemmEpi e = epi(h->bpatch, ws.x, nullptr, D);
     e.pos = h->pos_hw; e.rows_per_img = Np; e.out_rows_per_img = N;
     rc = linear(h, bf, ws.hbuf, h->Kp, h->Wpatch, h->Kp, B * Np, D, h->Kp, e, s); if (rc) return rc;
+  }
   }
   KCHK(h, launch_cls_row(h->cls, h->pos_hw, ws.x, B, N, D, s));
   tap(h, 0, ws.x, false, (size_t)M * D, s);
@@ -585,6 +609,8 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
   if (dh > 128 || dh % 4) return fail(h, DOD_ERR_INVALID, "decoder head_dim %d unsupported (<=128, multiple of 4)", dh);
   int rc;
   tap(h, 1000, mem_op, bf, (size_t)M * Dd, s);
+  const bool x3 = is_x3(h) && ws.mem2;
+  if (x3) KCHK(h, launch_split2((const float*)mem_op, Dd, ws.mem2, M, Dd, s));   // memory-side projections as split products
   KCHK(h, launch_bcast_rows(h->query, ws.tgt, 1, Q, Dd, s));                                                  // K10 (image 0; broadcast after layer 0's shared part)
   int fh = 0, fw = 0;
   if (g.use_deformable) {
@@ -594,14 +620,16 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
       DLayer& L = h->DL[j];
       if (L.vp_alias >= 0) continue;
       float* dst = ws.values + (size_t)u * M * Dd; ++u;
-      rc = linear(h, bf, mem_op, Dd, L.vp_w, Dd, M, Dd, Dd, epi(L.vp_b, dst, nullptr, Dd), s); if (rc) return rc;
+      if (x3 && L.vp_w2) rc = linear3(h, ws.mem2, L.vp_w2, M, Dd, Dd, epi(L.vp_b, dst, nullptr, Dd), s);
+      else rc = linear(h, bf, mem_op, Dd, L.vp_w, Dd, M, Dd, Dd, epi(L.vp_b, dst, nullptr, Dd), s);
+      if (rc) return rc;
     }
     tap(h, 2000, ws.values, false, (size_t)M * Dd, s);
   }
   const float sscale = 1.0f / std::sqrt((float)dh);
   // query-side linear: fp32 MFMA kernel, or (bf16 mode, large enough, N % 4 == 0) the bf16x3-split form on the bf16 kernel
   auto qlinear = [&](const float* A, int K, const float* Wf, const bf16_t* W3, int rows, int Nout, const GemmEpi& e) -> int {
-    if (bf && W3 && ws.a3 && rows >= 1024 && Nout >= 128 && Nout % 4 == 0 && e.ldc % 4 == 0 && e.act != ACT_SIGMOID) {
+    if ((bf || x3) && W3 && ws.a3 && rows >= 1024 && Nout >= 128 && Nout % 4 == 0 && e.ldc % 4 == 0 && e.act != ACT_SIGMOID) {
       KCHK(h, launch_split3(A, K, ws.a3, rows, K, 0, s));
       return linear(h, true, ws.a3, 3 * K, W3, 3 * K, rows, Nout, 3 * K, e, s);
     }
@@ -644,7 +672,9 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
       // K20: dense cross-attention over all N memory tokens
       if (shared0) KCHK(h, launch_bcast_rows(ws.tgt, ws.tgt + (size_t)Q * Dd, B - 1, Q, Dd, s));
       rc = qlinear(ws.tgt, Dd, L.ca_q_w, L.ca_q_w3, BQ, Dd, epi(L.ca_q_b, ws.qd, nullptr, Dd)); if (rc) return rc;
-      rc = linear(h, bf, mem_op, Dd, L.ca_kv_w, Dd, M, 2 * Dd, Dd, epi(L.ca_kv_b, ws.kv, nullptr, 2 * Dd), s); if (rc) return rc;
+      if (x3 && L.ca_kv_w2) rc = linear3(h, ws.mem2, L.ca_kv_w2, M, 2 * Dd, Dd, epi(L.ca_kv_b, ws.kv, nullptr, 2 * Dd), s);
+      else rc = linear(h, bf, mem_op, Dd, L.ca_kv_w, Dd, M, 2 * Dd, Dd, epi(L.ca_kv_b, ws.kv, nullptr, 2 * Dd), s);
+      if (rc) return rc;
       AttnF32 a; a.q = ws.qd; a.k = ws.kv; a.v = ws.kv + Dd; a.o = ws.att; a.ldq = Dd; a.ldk = a.ldv = 2 * Dd; a.ldo = Dd;
       a.Lq = Q; a.Lk = N; a.B = B; a.heads = Hd; a.dh = dh; a.scale = sscale;
       KCHK(h, launch_attn_f32(a, s));
