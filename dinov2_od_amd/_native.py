@@ -63,6 +63,7 @@ SYMBOLS = {
     "dod_op_im2col": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "dod_postprocess_workspace_bytes": (_SZ, [_I, _I, _I]),
     "dod_postprocess": (_I, [_P, _I, _I, _I, _P, _F, _P, C.c_int64, _P, _P, _SZ, _P]),
+    "dod_preprocess": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "dod_match_cost": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P, _P]),
     "dod_debug_gemm_stamps": (_I, [_P]),
     "dod_debug_attn_stamps": (_I, [_P]),

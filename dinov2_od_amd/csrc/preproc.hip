@@ -1,0 +1,127 @@
+// Input pipeline on device: the reference's transform (dino_detector/train.py:584-587),
+// torchvision Resize((R, R)) + ToTensor() on a PIL image, for a ragged batch of uint8 HWC RGB images:
+//   Image.resize((R, R), BILINEAR)  ->  uint8 [R, R, 3]  ->  float32 CHW / 255.
+// The arithmetic is Pillow's (src/libImaging/Resample.c; third-party, restated -- see oracle/preprocess_oracle.py): per output
+// index a window [xmin, xmin + n) with bilinear weights computed in DOUBLE (support = max(scale, 1): the filter widens when
+// downscaling), normalised, converted to int32 fixed point (22 bits, round half away from zero); a horizontal pass into a
+// uint8 image (accumulator seeded with 1 << 21, >> 22, clipped), then a vertical pass on that uint8 image.  Integer / byte
+// work, bit-exact: the double-precision weight arithmetic is compiled without FMA contraction so it rounds like the C code.
+// (Pillow skips a pass whose size does not change; that pass is the identity here too -- weights (1 << 22, 0) -- so both
+//  passes always run.)  HBM-bound byte work: each source byte is read once per pass (windows overlap in L2), lanes run along
+// the contiguous output bytes.
+#include "dod_common.h"
+#include "../../include/dinodet.h"
+
+#define PP_BITS 22
+#define PP_MAXK 32          // window taps: ceil(max(scale, 1)) * 2 + 1 <= 32  (down-scaling up to 15x)
+
+// window and fixed-point weights of output index xx (Resample.c precompute_coeffs + normalize_coeffs_8bpc)
+__device__ void pil_coeffs(int in_size, int out_size, int xx, int* lo, int* n, int* kk) {
+#pragma clang fp contract(off)
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;
+  const double center = 0.0 + ((double)xx + 0.5) * scale;
+  const double ss = 1.0 / filterscale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  if (xmax > PP_MAXK) xmax = PP_MAXK;          // unreachable: the host wrapper bounds the scale
+  double ww = 0.0;
+  for (int x = 0; x < xmax; ++x) {
+    double t = ((double)(x + xmin) - center + 0.5) * ss;
+    if (t < 0.0) t = -t;
+    ww += t < 1.0 ? 1.0 - t : 0.0;
+  }
+  for (int x = 0; x < xmax; ++x) {
+    double t = ((double)(x + xmin) - center + 0.5) * ss;
+    if (t < 0.0) t = -t;
+    double w = t < 1.0 ? 1.0 - t : 0.0;
+    if (ww != 0.0) w /= ww;
+    const double v = w * (double)(1 << PP_BITS);
+    kk[x] = w < 0.0 ? (int)(-0.5 + v) : (int)(0.5 + v);
+  }
+  *lo = xmin;
+  *n = xmax;
+}
+
+__device__ __forceinline__ unsigned char pp_clip8(int acc) {
+  const int v = acc >> PP_BITS;
+  return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// horizontal pass: tmp[b][y][ox][c].  Block = 256 output columns x PP_ROWS source rows of one image.
+#define PP_ROWS 16
+__global__ __launch_bounds__(256) void pp_horizontal_kernel(const unsigned char* __restrict__ src,
+                                                            const long long* __restrict__ src_offs,
+                                                            const int* __restrict__ hs, const int* __restrict__ ws, int out_w,
+                                                            unsigned char* __restrict__ tmp,
+                                                            const long long* __restrict__ tmp_offs) {
+  __shared__ int kk[256][PP_MAXK + 1];      // +1: odd pitch, conflict-free per-thread rows
+  const int b = blockIdx.z;
+  const int H = hs[b], W = ws[b];
+  const int y0 = blockIdx.y * PP_ROWS;
+  if (y0 >= H) return;
+  const int ox = blockIdx.x * 256 + threadIdx.x;
+  if (ox >= out_w) return;
+  int lo, n;
+  pil_coeffs(W, out_w, ox, &lo, &n, kk[threadIdx.x]);
+  const unsigned char* img = src + src_offs[b];
+  unsigned char* dst = tmp + tmp_offs[b];
+  const int y1 = y0 + PP_ROWS < H ? y0 + PP_ROWS : H;
+  for (int y = y0; y < y1; ++y) {
+    const unsigned char* row = img + ((size_t)y * W + lo) * 3;
+    int a0 = 1 << (PP_BITS - 1), a1 = a0, a2 = a0;
+    for (int x = 0; x < n; ++x) {
+      const int k = kk[threadIdx.x][x];
+      a0 += (int)row[3 * x] * k; a1 += (int)row[3 * x + 1] * k; a2 += (int)row[3 * x + 2] * k;
+    }
+    unsigned char* o = dst + ((size_t)y * out_w + ox) * 3;
+    o[0] = pp_clip8(a0); o[1] = pp_clip8(a1); o[2] = pp_clip8(a2);
+  }
+}
+
+// vertical pass + ToTensor: out[b][c][oy][ox] = clip8(...) / 255.  Block = one output row; threads along its 3*out_w bytes.
+__global__ __launch_bounds__(256) void pp_vertical_kernel(const unsigned char* __restrict__ tmp,
+                                                          const long long* __restrict__ tmp_offs,
+                                                          const int* __restrict__ hs, int out_h, int out_w,
+                                                          float* __restrict__ out) {
+  __shared__ int kk[PP_MAXK];
+  __shared__ int s_lo, s_n;
+  const int b = blockIdx.y, oy = blockIdx.x;
+  const int H = hs[b];
+  if (threadIdx.x == 0) {
+    int lo, n;
+    pil_coeffs(H, out_h, oy, &lo, &n, kk);
+    s_lo = lo; s_n = n;
+  }
+  __syncthreads();
+  const int lo = s_lo, n = s_n;
+  const unsigned char* img = tmp + tmp_offs[b];
+  const int rowbytes = out_w * 3;
+  for (int t = threadIdx.x; t < rowbytes; t += 256) {
+    int acc = 1 << (PP_BITS - 1);
+    for (int y = 0; y < n; ++y) acc += (int)img[(size_t)(lo + y) * rowbytes + t] * kk[y];
+    const int ox = t / 3, c = t - ox * 3;
+    out[(((size_t)b * 3 + c) * out_h + oy) * out_w + ox] = (float)pp_clip8(acc) / 255.0f;
+  }
+}
+
+extern "C" int dod_preprocess(const uint8_t* src, const int64_t* src_offs, const int32_t* heights, const int32_t* widths, int B,
+                              int max_h, int max_w, int out_h, int out_w, uint8_t* tmp, const int64_t* tmp_offs, float* out,
+                              void* stream) {
+  if (!src || !src_offs || !heights || !widths || !tmp || !tmp_offs || !out) return DOD_ERR_INVALID;
+  if (B <= 0 || out_h <= 0 || out_w <= 0 || max_h <= 0 || max_w <= 0 || B > 65535) return DOD_ERR_INVALID;
+  // window taps ceil(max(scale, 1)) * 2 + 1 must fit PP_MAXK
+  const int kh = ((max_w + out_w - 1) / out_w) * 2 + 1, kv = ((max_h + out_h - 1) / out_h) * 2 + 1;
+  if (kh > PP_MAXK || kv > PP_MAXK) return DOD_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(pp_horizontal_kernel, dim3((out_w + 255) / 256, (max_h + PP_ROWS - 1) / PP_ROWS, B), dim3(256), 0, s,
+                     (const unsigned char*)src, (const long long*)src_offs, heights, widths, out_w, (unsigned char*)tmp,
+                     (const long long*)tmp_offs);
+  hipLaunchKernelGGL(pp_vertical_kernel, dim3(out_h, B), dim3(256), 0, s, (const unsigned char*)tmp, (const long long*)tmp_offs,
+                     heights, out_h, out_w, out);
+  return hipGetLastError() == hipSuccess ? DOD_OK : DOD_ERR_HIP;
+}

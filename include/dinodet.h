@@ -183,6 +183,17 @@ int dod_postprocess(const float* det, int B, int Q, int C, const int64_t* image_
                     dod_detection* out, int64_t max_out, int64_t* count, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* ---- input pipeline on device -------------------------------------------------------
+ * Replaces the per-image host transform of dino_detector/train.py:584-587 -- torchvision Resize((R,R)) + ToTensor() on a
+ * PIL image, i.e. Pillow's Image.resize(BILINEAR) (two-pass 8-bit fixed-point resample, antialiased when downscaling)
+ * followed by uint8 -> float32 / 255 in CHW order -- for a ragged batch.  Bit-exact against Pillow.
+ * src: concatenated uint8 HWC RGB images, image b at src + src_offs[b] with heights[b] x widths[b] pixels; tmp: the
+ * horizontal-pass images, image b at tmp + tmp_offs[b] (heights[b] * out_w * 3 bytes); out: fp32 [B, 3, out_h, out_w].
+ * All pointers are device pointers; max_h / max_w (host) bound the grid and the filter width (scale <= 15). */
+int dod_preprocess(const uint8_t* src, const int64_t* src_offs, const int32_t* heights, const int32_t* widths, int B,
+                   int max_h, int max_w, int out_h, int out_w, uint8_t* tmp, const int64_t* tmp_offs, float* out,
+                   void* stream);
+
 /* ---- Hungarian-matcher cost matrices on device -------------------------------------
  * Replaces the per-image cost computation of HungarianMatcher.forward, dino_detector/matching.py:79-98 (focal class
  * cost :80-86, L1 box cost :89, GIoU cost :92-95 with utils.py:124-164, weighted sum :98) for the whole batch.

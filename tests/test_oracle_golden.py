@@ -125,3 +125,21 @@ def test_matching_oracle_matches_reference_matcher(tag, kw):
             assert np.max(np.abs(costs[b] - want)) <= 1e-6 * max(1.0, np.abs(want).max())
         assert np.array_equal(idx[b][0], g[f"{tag}_i{b}"]) and np.array_equal(idx[b][1], g[f"{tag}_j{b}"])
     assert g["default_cost1"].shape == (det.shape[1], 0) and list(g["emptydict_n0"]) == [0, 0]
+
+
+@pytest.mark.parametrize("hw", [(480, 640), (427, 640), (333, 500), (224, 224), (100, 80), (518, 700), (1000, 37), (225, 223)])
+@pytest.mark.parametrize("out", [(224, 224), (518, 518)])
+def test_preprocess_oracle_matches_pillow(hw, out):
+    """f4: the restated Pillow BILINEAR resample (8-bit, two-pass fixed point) is bit-exact against Pillow itself"""
+    from PIL import Image
+    from oracle import preprocess_oracle as ppo
+    rng = np.random.default_rng(hw[0] * 1000 + hw[1])
+    img = rng.integers(0, 256, size=(hw[0], hw[1], 3), dtype=np.uint8)
+    if hw[0] == 333:
+        img[:, ::2] = 255          # hard edges: exercises rounding / clipping
+        img[:, 1::2] = 0
+    want = np.array(Image.fromarray(img, "RGB").resize((out[1], out[0]), Image.BILINEAR))
+    got = ppo.resize_bilinear_u8(img, out[0], out[1])
+    assert got.shape == want.shape and np.array_equal(got, want)
+    t = ppo.to_tensor(got)
+    assert t.shape == (3, out[0], out[1]) and t.dtype == np.float32 and float(t.max()) <= 1.0
