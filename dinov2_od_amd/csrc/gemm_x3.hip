@@ -24,6 +24,9 @@
 
 __device__ __forceinline__ int x3_swz(int row, int chunk) { return chunk ^ (((row >> 3) & 1) << 1); }   // 16x16x32 lane map, 64-B rows
 
+// PLAIN = true: the same structure as an ordinary bf16 GEMM with BK = 64 -- the second plane of each operand holds k 32..63
+// of the K-tile instead of the lo halves, two products per K-tile (experiment / DINODET_GEMM_TILE=x).
+template <bool PLAIN>
 __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __restrict__ A2, int lda,
                                                                const bf16_t* __restrict__ W2, int ldw, int M, int N,
                                                                int K, GemmEpi e, int GM) {
@@ -64,16 +67,17 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
   {                                                                                                        \
     char* s_ = smem + (slot_) * X3_STAGE + wu * 1024;                                                      \
     __builtin_amdgcn_global_load_lds((gptr_t)(gA + (k0)), (lptr_t)(s_), 16, 0, 0);                         \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA + K + (k0)), (lptr_t)(s_ + X3_PLANE), 16, 0, 0);          \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA + (PLAIN ? 32 : K) + (k0)), (lptr_t)(s_ + X3_PLANE), 16, 0, 0); \
     __builtin_amdgcn_global_load_lds((gptr_t)(gW + (k0)), (lptr_t)(s_ + 2 * X3_PLANE), 16, 0, 0);          \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gW + K + (k0)), (lptr_t)(s_ + 3 * X3_PLANE), 16, 0, 0);      \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW + (PLAIN ? 32 : K) + (k0)), (lptr_t)(s_ + 3 * X3_PLANE), 16, 0, 0); \
   }
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nk = K / X3K;
+  constexpr int KSTEP = PLAIN ? 2 * X3K : X3K;
+  const int nk = K / KSTEP;
   const int l15 = lane & 15, l4 = lane >> 4;
   STAGE_X3(0, 0)
   int offA[4], offW[4];
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt landed (the only one in flight)
     __builtin_amdgcn_s_barrier();                         // ... for all waves, and all waves are done with tile kt-1
     asm volatile("" ::: "memory");
-    if (kt + 1 < nk) STAGE_X3((kt + 1) & 1, (kt + 1) * X3K)
+    if (kt + 1 < nk) STAGE_X3((kt + 1) & 1, (kt + 1) * KSTEP)
     const char* st = smem + (kt & 1) * X3_STAGE;
     bf16x8 wh[4], wl[4];
 #pragma unroll
@@ -99,9 +103,14 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
       const bf16x8 al = *reinterpret_cast<const bf16x8*>(st + offA[i] + X3_PLANE);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah, acc[i][j], 0, 0, 0);   // small terms first
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah, acc[i][j], 0, 0, 0);
+        if (PLAIN) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah, acc[i][j], 0, 0, 0);   // k 0..31
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], al, acc[i][j], 0, 0, 0);   // k 32..63
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah, acc[i][j], 0, 0, 0);   // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah, acc[i][j], 0, 0, 0);
+        }
       }
     }
   }
@@ -139,12 +148,28 @@ int launch_gemm_x3(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, 
   if (!e.out_f32 && !e.out_bf16) return 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
     attr_set = true;
   }
   static const char* gme = getenv("DINODET_GEMM_GM");
   const int gm = gme ? atoi(gme) : 4;
   const int tiles = ((M + X3M - 1) / X3M) * ((N + X3N - 1) / X3N);
-  hipLaunchKernelGGL(gemm_x3_256x256_kernel, dim3(tiles), dim3(1024), LDSX3, s, A2, lda, W2, ldw, M, N, K, e, gm);
+  hipLaunchKernelGGL(gemm_x3_256x256_kernel<false>, dim3(tiles), dim3(1024), LDSX3, s, A2, lda, W2, ldw, M, N, K, e, gm);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// plain bf16 GEMM on the same structure (256x256x64, 16 waves, two 64-KiB slots): K % 64 == 0
+int launch_gemm_bf16_k64(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 64 != 0) return 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
+    attr_set = true;
+  }
+  static const char* gme = getenv("DINODET_GEMM_GM");
+  const int gm = gme ? atoi(gme) : 4;
+  const int tiles = ((M + X3M - 1) / X3M) * ((N + X3N - 1) / X3N);
+  hipLaunchKernelGGL(gemm_x3_256x256_kernel<true>, dim3(tiles), dim3(1024), LDSX3, s, A, lda, W, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
