@@ -55,6 +55,9 @@ SYMBOLS = {
     "dod_op_linear": (_I, [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "dod_op_linear_fp8": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "dod_op_quant_rows_fp8": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "dod_op_split_pair": (_I, [_P, _I, _I, _I, _P, _P]),
+    "dod_op_linear_x3": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "dod_op_attention_x3": (_I, [_P, _P, _I, _I, _I, _F, _P]),
     "dod_op_layernorm": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _I, _P]),
     "dod_op_attention_bf16": (_I, [_P, _P, _I, _I, _I, _F, _P]),
     "dod_op_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),

@@ -629,7 +629,8 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
   const float sscale = 1.0f / std::sqrt((float)dh);
   // query-side linear: fp32 MFMA kernel, or (bf16 mode, large enough, N % 4 == 0) the bf16x3-split form on the bf16 kernel
   auto qlinear = [&](const float* A, int K, const float* Wf, const bf16_t* W3, int rows, int Nout, const GemmEpi& e) -> int {
-    if ((bf || x3) && W3 && ws.a3 && rows >= 1024 && Nout >= 128 && Nout % 4 == 0 && e.ldc % 4 == 0 && e.act != ACT_SIGMOID) {
+    static const int qrows = getenv("DINODET_QSPLIT_ROWS") ? atoi(getenv("DINODET_QSPLIT_ROWS")) : 1024;   // tuning
+    if ((bf || x3) && W3 && ws.a3 && rows >= qrows && Nout >= 128 && Nout % 4 == 0 && e.ldc % 4 == 0 && e.act != ACT_SIGMOID) {
       KCHK(h, launch_split3(A, K, ws.a3, rows, K, 0, s));
       return linear(h, true, ws.a3, 3 * K, W3, 3 * K, rows, Nout, 3 * K, e, s);
     }
@@ -938,6 +939,25 @@ int dod_op_linear_fp8(const void* A, int lda, const float* a_scale, const void* 
   e.a_scale = a_scale; e.w_scale = w_scale;
   int r = launch_gemm_fp8((const unsigned char*)A, lda, (const unsigned char*)W, ldw, M, N, K, e, (hipStream_t)stream);
   if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear_fp8 rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
+  return DOD_OK;
+}
+int dod_op_split_pair(const float* x, int ld, int rows, int cols, void* out, void* stream) {
+  if (!x || !out) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  return launch_split2(x, ld, (bf16_t*)out, rows, cols, (hipStream_t)stream) ? fail(nullptr, DOD_ERR_HIP, "launch failed") : DOD_OK;
+}
+int dod_op_linear_x3(const void* A2, const void* W2, int M, int N, int K, const float* bias, const float* scale, const float* resid, int ldr,
+                     void* out, int out_layout, int ldc, int act, void* stream) {
+  if (!A2 || !W2 || !out) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  GemmEpi e = epi(bias, out_layout == 0 ? (float*)out : nullptr, out_layout != 0 ? out : nullptr, ldc, act, scale, resid, ldr);
+  if (out_layout == 2) e.out_split = -N;       // pair layout [hi | lo]
+  int r = launch_gemm_x3((const bf16_t*)A2, 2 * K, (const bf16_t*)W2, 2 * K, M, N, K, e, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear_x3 rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
+  return DOD_OK;
+}
+int dod_op_attention_x3(const void* qkv2, void* ctx2, int B, int N, int heads, float scale, void* stream) {
+  if (!qkv2 || !ctx2) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  int r = launch_attn_x3((const bf16_t*)qkv2, (bf16_t*)ctx2, B, N, heads, scale, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_attention_x3 rejected");
   return DOD_OK;
 }
 int dod_op_quant_rows_fp8(const void* x, int in_dtype, int ld, int rows, int cols, void* q, int ldq, float* scale, void* stream) {

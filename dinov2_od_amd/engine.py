@@ -42,6 +42,10 @@ class Engine:
         self._ws = None
         self._keep = []     # tensors whose pointers the handle holds until finalize returns
         self._tap_bufs = {}
+        # hipGraph replay of the whole forward, one captured graph per input shape (opt-in: DINODET_HIPGRAPH=1 or
+        # model.enable_hipgraph()): ~100 launches per forward are launch-bound at small batch
+        self.use_graph = os.environ.get("DINODET_HIPGRAPH", "0") == "1"
+        self._graphs = {}   # (B, H, W, device) -> (graph, static input, static output)
 
     def close(self):
         if self._h:
@@ -78,6 +82,7 @@ class Engine:
         self._keep = []
         self._sig = sig
         self._ws = None
+        self._graphs = {}       # packed weights were reallocated: captured graphs hold stale pointers
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, nbytes, device):
@@ -97,9 +102,25 @@ class Engine:
             raise RuntimeError("pixel_values must be on the GPU: the MI355X path has no CPU fallback")
         return x.detach().to(torch.float32).contiguous()
 
-    def forward(self, pixel_values, named):
-        x = self._check_pixels(pixel_values)
-        self.sync_weights(named)
+    def _forward_graph(self, x):
+        """replay (capturing on first use) the forward for x's shape; returns the graph's static output buffer"""
+        key = (tuple(x.shape), x.device)
+        ent = self._graphs.get(key)
+        if ent is None:
+            xs = x.clone()
+            self._launch_forward(xs)                       # warm-up outside capture: position table, func attributes, workspace
+            torch.cuda.synchronize(x.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                out = self._launch_forward(xs)
+            ent = (g, xs, out)
+            self._graphs[key] = ent
+        g, xs, out = ent
+        xs.copy_(x)
+        g.replay()
+        return out
+
+    def _launch_forward(self, x):
         B, _, H, W = x.shape
         nbytes = self._lib.dod_workspace_bytes(self._h, B, H, W)
         if nbytes == 0:
@@ -109,6 +130,13 @@ class Engine:
         nat.check(self._lib.dod_forward(self._h, nat.ptr(x), B, H, W, nat.ptr(det), nat.ptr(ws), ws.numel(),
                                         nat.stream_ptr()), self._h)
         return det
+
+    def forward(self, pixel_values, named):
+        x = self._check_pixels(pixel_values)
+        self.sync_weights(named)
+        if self.use_graph and not torch.cuda.is_current_stream_capturing() and not self._tap_bufs:
+            return self._forward_graph(x)
+        return self._launch_forward(x)
 
     def backbone_forward(self, pixel_values, named):
         x = self._check_pixels(pixel_values)

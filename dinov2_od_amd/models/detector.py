@@ -49,6 +49,12 @@ class DINOv2ObjectDetector(nn.Module, _EngineMixin):
     def _engine_named(self):
         return list(self.state_dict(keep_vars=True).items())    # keys already "backbone." / "decoder."
 
+    def enable_hipgraph(self, on=True):
+        """eval-mode forwards replay one captured hipGraph per input shape (the returned tensors are the graph's static output
+        buffer: consume or clone them before the next forward of the same shape)"""
+        self._get_engine().use_graph = bool(on)
+        return self
+
     def forward_packed(self, pixel_values):
         """[B,3,H,W] -> packed detections [B, Q, C+4] (logits | boxes): the buffer the multi-GPU
         all-gather moves (dinov2_od_amd.dist.gather_detections)."""

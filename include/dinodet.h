@@ -147,6 +147,15 @@ int dod_op_linear_fp8(const void* A, int lda, const float* a_scale, const void* 
  * row); q = round-to-nearest-even e4m3 of x / scale */
 int dod_op_quant_rows_fp8(const void* x, int in_dtype, int ld, int rows, int cols, void* q, int ldq, float* scale,
                           void* stream);
+/* bf16x3 (parity-gated mode) operators.  Pair layout: [rows, 2*cols] bf16 = [hi | lo], hi = bf16(x), lo = bf16(x - hi).
+ * dod_op_split_pair: fp32 x [rows, cols] (ld) -> pair layout.
+ * dod_op_linear_x3: A2 [M, 2K], W2 [N, 2K] pair layouts -> act(A W^T + bias) * scale + resid as the split product
+ *   Ah Wh^T + Ah Wl^T + Al Wh^T; out_layout 0: fp32 [M, ldc], 1: bf16 [M, ldc], 2: pair layout [M, 2N] (ldc = 2N).
+ * dod_op_attention_x3: qkv2 [B*N, 6*D] = [hi(q|k|v) | lo(q|k|v)] -> ctx2 [B*N, 2*D] pair layout, head_dim 64. */
+int dod_op_split_pair(const float* x, int ld, int rows, int cols, void* out, void* stream);
+int dod_op_linear_x3(const void* A2, const void* W2, int M, int N, int K, const float* bias, const float* scale,
+                     const float* resid, int ldr, void* out, int out_layout, int ldc, int act, void* stream);
+int dod_op_attention_x3(const void* qkv2, void* ctx2, int B, int N, int heads, float scale, void* stream);
 /* out = LayerNorm(x + add) ; add may be NULL */
 int dod_op_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, void* out, int out_dtype, void* stream);

@@ -233,6 +233,30 @@ def test_train_step_then_native_eval(G):
     assert rel_err(comp["pred_logits"].cpu().numpy(), after[..., :91].cpu().numpy()) < TOL
 
 
+def test_hipgraph_replay_matches_eager_and_tracks_weight_updates(G):
+    """model.enable_hipgraph(): one captured graph per input shape, bit-identical to the eager launches, re-captured after a
+    weight update (the packed weights move), several shapes side by side."""
+    bb, dc = cases.cfg1(25)
+    m = G.make_detector(bb, dc, "bf16", "facebook/dinov2-small")
+    xa = G.to_gpu(synth.make_pixels(2, 224, 224, seed=0))
+    xb = G.to_gpu(synth.make_pixels(1, 70, 112, seed=3))
+    ea, eb = m.forward_packed(xa).clone(), m.forward_packed(xb).clone()
+    m.enable_hipgraph()
+    for _ in range(2):                                   # first call captures, second replays
+        assert torch.equal(m.forward_packed(xa), ea)
+        assert torch.equal(m.forward_packed(xb), eb)
+    xa2 = G.to_gpu(synth.make_pixels(2, 224, 224, seed=5))
+    m.enable_hipgraph(False)
+    ea2 = m.forward_packed(xa2).clone()
+    m.enable_hipgraph()
+    assert torch.equal(m.forward_packed(xa2), ea2)       # new input through the static buffer
+    sd2 = synth.detector_state_dict(bb, dc, seed=2)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()}, strict=True)
+    g2 = m.forward_packed(xa).clone()
+    m.enable_hipgraph(False)
+    assert torch.equal(m.forward_packed(xa), g2) and not torch.equal(g2, ea)
+
+
 def test_module_prefix_and_error_paths(G):
     from dinov2_od_amd import _native as nat
     bb, dc = cases.cfg1(25)
