@@ -485,12 +485,10 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
     int r = launch_gemm_x3((const bf16_t*)ws.qkv, 2 * K2, h->Wpatch2, 2 * K2, B * Np, D, K2, e, s);
     if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "split patch-embed GEMM rejected (rc %d)", r);
   } else {
-  KCHK(h, launch_im2col(pixels, B, H, W, p, h->Kp, bf ? nullptr : (float*)ws.hbuf, bf ? (bf16_t*)ws.hbuf : nullptr, s));
-  {
+    KCHK(h, launch_im2col(pixels, B, H, W, p, h->Kp, bf ? nullptr : (float*)ws.hbuf, bf ? (bf16_t*)ws.hbuf : nullptr, s));
     GemmEpi e = epi(h->bpatch, ws.x, nullptr, D);
     e.pos = h->pos_hw; e.rows_per_img = Np; e.out_rows_per_img = N;
     rc = linear(h, bf, ws.hbuf, h->Kp, h->Wpatch, h->Kp, B * Np, D, h->Kp, e, s); if (rc) return rc;
-  }
   }
   KCHK(h, launch_cls_row(h->cls, h->pos_hw, ws.x, B, N, D, s));
   tap(h, 0, ws.x, false, (size_t)M * D, s);
@@ -540,8 +538,8 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
       { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, nullptr, nullptr, s, (unsigned char*)ws.y, ws.rs)); }
       rc = linear8(h, ws.y, ws.rs, L.Wqkv, L.sqkv, M, 3 * D, D, epi(L.bqkv, nullptr, ws.qkv, 3 * D), s); if (rc) return rc;
     } else {
-    { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, yf, yb, s)); }   // K3
-    rc = linear(h, bf, ws.y, D, L.Wqkv, D, M, 3 * D, D, epi(L.bqkv, bf ? nullptr : (float*)ws.qkv, bf ? ws.qkv : nullptr, 3 * D), s); if (rc) return rc;  // K4
+      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, yf, yb, s)); }   // K3
+      rc = linear(h, bf, ws.y, D, L.Wqkv, D, M, 3 * D, D, epi(L.bqkv, bf ? nullptr : (float*)ws.qkv, bf ? ws.qkv : nullptr, 3 * D), s); if (rc) return rc;  // K4
     }
     if (bf) { ProfScope ps(h, s, PC_ATTN_BF16, 4.0 * B * (double)N * N * D); KCHK(h, launch_attn_bf16((const bf16_t*)ws.qkv, (bf16_t*)ws.ctx, B, N, g.heads, scale, s)); }    // K5
     else {
