@@ -294,7 +294,7 @@ def test_bf16_decoder_split3_linears_large_batch(G):
 
 
 @pytest.mark.parametrize("variant", ["large", "giant"])
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_large_and_giant_shaped_models_two_blocks(G, variant, precision):
     """BASELINE configs[3]/[4] shapes at reduced depth (2 encoder blocks): ViT-L (hidden 1024, 16 heads) and ViT-g
     (hidden 1536, 24 heads, SwiGLU 4096) with the 768-wide projection and a 300-query decoder, 224x224 input.
@@ -312,7 +312,7 @@ def test_large_and_giant_shaped_models_two_blocks(G, variant, precision):
     out = m(G.to_gpu(x))
     G.sync()
     assert out["pred_logits"].shape == (2, 300, 91)
-    if precision == "fp32":
+    if precision in GATED:
         want = orc.detector_forward(sd, bb, dc, x)
         assert rel_err(mem.cpu().numpy(), want["features"].numpy()) < 1e-4
         # 300 queries on the (1, 257) grid of a 224x224 input: each decoder layer amplifies a perturbation ~10x
@@ -323,7 +323,8 @@ def test_large_and_giant_shaped_models_two_blocks(G, variant, precision):
         for k in ("pred_logits", "pred_boxes"):
             floor = rel_err(want[k].numpy(), exact[k].numpy())
             got = rel_err(out[k].cpu().numpy(), exact[k].numpy())
-            assert got < max(TOL, 3.0 * floor), (k, got, floor)
+            # bf16x3 carries 16 mantissa bits per operand (features 3e-5 instead of 1e-6): one more factor on this config
+            assert got < max(TOL, (3.0 if precision == "fp32" else 5.0) * floor), (k, got, floor)
     else:
         want = orc.detector_forward(sd, bb, dc, x, emulate_bf16=True)
         assert rel_l2(mem.cpu().numpy(), want["features"].numpy()) < 8e-3
