@@ -71,6 +71,7 @@ SYMBOLS = {
     "dod_debug_gemm_stamps": (_I, [_P]),
     "dod_debug_attn_stamps": (_I, [_P]),
     "dod_debug_mfma_peak": (_I, [_I, _I, _I, _P, _P]),
+    "dod_debug_mfma_valu_probe": (_I, [_I, _I, _I, _I, _P, _P]),
     "dod_version": (C.c_char_p, []),
     "dod_device_count": (_I, []),
 }

@@ -875,3 +875,56 @@ extern "C" int dod_debug_mfma_peak(int shape, int iters, int blocks, void* dev_o
   else hipLaunchKernelGGL(mfma_peak_kernel<32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)dev_out);
   return hipGetLastError() == hipSuccess ? 0 : 4;
 }
+
+// MFMA / VALU co-issue probe (tools/mfma_peak.py): per iteration 4 independent v_mfma_f32_32x32x16_bf16 (mode & 1) and
+// `nvalu` independent v_fma_f32 chains stepped once each (mode & 2), interleaved one MFMA : nvalu/4 VALU by the asm order.
+template <int NV, int mode>
+__global__ __launch_bounds__(256, 2) void mfma_valu_probe_kernel(int iters, unsigned long long* out) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (bf16_t)(0x3c00 + threadIdx.x + i); b[i] = (bf16_t)(0x3c10 + threadIdx.x * 3 + i); }
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = 1.0f + 0.001f * (threadIdx.x + i);
+  const float m = 0.999f, c = 0.001f;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (mode & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[q]) : "v"(a), "v"(b));
+      if (mode & 2) {
+#pragma unroll
+        for (int i = 0; i < NV / 4; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[q * (NV / 4) + i]) : "v"(m), "v"(c));
+      }
+    }
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  float chk = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) chk += acc[i][0];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) chk += v[i];
+  if (threadIdx.x == 0) { out[(size_t)blockIdx.x * 4] = c1 - c0; out[(size_t)blockIdx.x * 4 + 2] = (unsigned long long)__float_as_uint(chk); }
+}
+template <int NV>
+static int probe_launch(int mode, int iters, int blocks, void* dev_out, void* stream) {
+  unsigned long long* o = (unsigned long long*)dev_out;
+  if (mode == 1) hipLaunchKernelGGL((mfma_valu_probe_kernel<NV, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, o);
+  else if (mode == 2) hipLaunchKernelGGL((mfma_valu_probe_kernel<NV, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, o);
+  else if (mode == 3) hipLaunchKernelGGL((mfma_valu_probe_kernel<NV, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, o);
+  else return 1;
+  return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+extern "C" int dod_debug_mfma_valu_probe(int nvalu, int mode, int iters, int blocks, void* dev_out, void* stream) {
+  if (!dev_out || iters <= 0 || blocks <= 0) return 1;
+  if (nvalu == 16) return probe_launch<16>(mode, iters, blocks, dev_out, stream);
+  if (nvalu == 28) return probe_launch<28>(mode, iters, blocks, dev_out, stream);
+  if (nvalu == 56) return probe_launch<56>(mode, iters, blocks, dev_out, stream);
+  return 1;
+}
+

@@ -224,6 +224,9 @@ int dod_debug_attn_stamps(void* dev_buf);
  * 4 waves, `iters` rounds; dev_out[block*4 + {0,1}] = {shader cycles, 100-MHz ticks}.  Measures the SUSTAINED matrix rate and
  * clock of the part under MFMA load (tools/mfma_peak.py); not used by the forward. */
 int dod_debug_mfma_peak(int shape, int iters, int blocks, void* dev_out, void* stream);
+/* MFMA / VALU co-issue probe: per iteration 4 independent 32x32x16 MFMAs (mode & 1) and nvalu (16 | 28 | 56) independent
+ * v_fma_f32 (mode & 2), interleaved; dev_out[block*4] = shader cycles of wave 0 (tools/mfma_peak.py). */
+int dod_debug_mfma_valu_probe(int nvalu, int mode, int iters, int blocks, void* dev_out, void* stream);
 
 const char* dod_version(void);
 /* Devices visible to the HIP runtime libdinodet.so is bound to (<= 0: none / error).  The host uses it to

@@ -26,3 +26,16 @@ for shape, chains, flop in ((16, 8, 2 * 16 * 16 * 32), (32, 4, 2 * 32 * 32 * 16)
         total = float(blocks) * 4 * iters * chains * flop
         print(f"mfma {shape}: {wg_per_cu} WG/CU ({wg_per_cu} waves/SIMD): {total / t / 1e12:7.1f} TFLOP/s wall; "
               f"s_memtime {cyc / (ticks / 100e6) / 1e9:5.2f} G counts/s; {cyc / (iters * chains):6.2f} counts per MFMA per wave")
+
+print("MFMA / VALU co-issue probe (4 x 32x32x16 MFMA = 128 MFMA cycles per iteration; v_fma_f32 = 4 issue cycles each):")
+for wg_per_cu in (1, 2):
+    for nv in (16, 28, 56):
+        row = []
+        for mode in (1, 2, 3):
+            blocks, iters = 256 * wg_per_cu, 20000
+            out = torch.zeros(blocks * 4, dtype=torch.int64, device=dev)
+            nat.check(L.dod_debug_mfma_valu_probe(nv, mode, iters, blocks, nat.ptr(out), nat.stream_ptr()))
+            torch.cuda.synchronize()
+            row.append(out.view(blocks, 4)[:, 0].double().median().item() / iters)
+        print(f"  {wg_per_cu} wave(s)/SIMD, {nv} VALU per iteration: MFMA only {row[0]:6.1f}, VALU only {row[1]:6.1f}, both {row[2]:6.1f} cycles/iteration "
+              f"(sum {row[0] + row[1]:6.1f}, max {max(row[0], row[1]):6.1f})")
