@@ -257,6 +257,26 @@ def test_hipgraph_replay_matches_eager_and_tracks_weight_updates(G):
     assert torch.equal(m.forward_packed(xa), g2) and not torch.equal(g2, ea)
 
 
+@pytest.mark.parametrize("precision", GATED + ["bf16"])
+def test_degenerate_images(G, precision):
+    """constant images (all zeros / all ones: identical patches, attention rows uniform) and a mixed batch: finite everywhere,
+    gated modes within the 1e-3 gate of the oracle, batch entries independent of their neighbours"""
+    bb, dc = cases.cfg1(25)
+    m = G.make_detector(bb, dc, precision, "facebook/dinov2-small")
+    x = np.zeros((3, 3, 224, 224), np.float32)
+    x[1] = 1.0
+    x[2] = synth.make_pixels(1, 224, 224, seed=0)[0]
+    out = m.forward_packed(G.to_gpu(x)).clone()
+    assert torch.isfinite(out).all()
+    single = m.forward_packed(G.to_gpu(x[1:2])).clone()
+    assert torch.equal(single[0], out[1]) or rel_err(single[0].cpu().numpy(), out[1].cpu().numpy()) < 1e-6
+    if precision in GATED:
+        sd = synth.detector_state_dict(bb, dc, seed=1)
+        want = orc.detector_forward(sd, bb, dc, x)
+        assert rel_err(out[..., :91].cpu().numpy(), want["pred_logits"].numpy()) < TOL
+        assert rel_err(out[..., 91:].cpu().numpy(), want["pred_boxes"].numpy()) < TOL
+
+
 def test_module_prefix_and_error_paths(G):
     from dinov2_od_amd import _native as nat
     bb, dc = cases.cfg1(25)
