@@ -780,9 +780,8 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   // 256x256x64, 16 waves, two 64-KiB slots (the structure of gemm_x3.hip with k 32..63 in the second planes): measured at
   // M = 87680 against the kernels below -- QKV 760 vs 700, out-proj 460 vs 423, fc2 765 vs 709 TFLOP/s; fc1 650 vs 652: with
   // one workgroup per CU nothing hides the GELU epilogue, so activations with a transcendental stay on the 2-workgroup kernel.
-  // (only when its 256x256 tiles still fill the 256 CUs at least twice: ViT-B at 224x224, batch 32 has 99..297 of them)
-  const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if (force ? force[0] == 'x' : (tiles256 >= 512 && N >= 512 && e.act != ACT_GELU && e.act != ACT_SIGMOID && e.rows_per_img == 0))
+  // (also at small grids: at M = 10960 -- batch 8 -- QKV 730 vs 639, out-proj 396 vs 375, fc2 634 vs 526 TFLOP/s)
+  if (force ? force[0] == 'x' : (M >= 4096 && N >= 512 && e.act != ACT_GELU && e.act != ACT_SIGMOID && e.rows_per_img == 0))
     return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
   // shape heuristic (measured on MI355X, tools/bench_gemm_k.py / bench_ops.py at M = 87680, random data):
   //   256x128x32 with v_mfma_f32_16x16x32_bf16, two workgroups per CU: QKV 703, out-proj 437, fc1 646, fc2 643 TFLOP/s
