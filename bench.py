@@ -16,7 +16,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
                  measured with HIP events on the launch stream by the library's profile mode over
                  extra forwards of the same step, right after the timed region;
   cpu_baseline : the CPU oracle (kind "port": oracle/dinodet_oracle.py, the parity-checked CPU
-                 restatement of the reference) timed on this box's host cores on a bounded sample.
+                 restatement of the reference) timed on this box's host cores on a bounded sample; its first
+                 batch also checks the GPU detections of the same two images (`gpu_vs_oracle`);
+  parity_gated_mode / fp32_mode : the same workload in the two modes that meet the 1e-3 gate (bf16x3: split
+                 products on the bf16 MFMA cores; fp32), each with its own `gpu_vs_oracle` (N = 1 only).
+Other workloads / modes: --workload {vits224,vitb224,vitl518,vitg518}, --precision {bf16,bf16x3,fp32,fp8}.
 """
 import argparse
 import json
