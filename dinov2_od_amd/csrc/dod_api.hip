@@ -20,7 +20,7 @@ struct WRef { const float* ptr; std::vector<int64_t> shape; size_t numel() const
 
 struct BLayer {
   void *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;   // bf16 or fp32 by precision (fp8 mode: Wqkv, W1 and the SwiGLU W2 are e4m3)
-  float *sqkv = nullptr, *s1 = nullptr, *s2 = nullptr;                 // fp8 mode: per-output-feature dequant scales
+  float *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;   // fp8 mode: per-output-feature dequant scales
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
   float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
 };
@@ -268,7 +268,9 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
     if (P.rc) break;
     const bool f8 = is_fp8(h), x3 = is_x3(h);
     L.Wqkv = x3 ? P.pair_w(cat, 3 * D, D) : f8 ? P.pack_fp8(cat, 3 * D, D, &L.sqkv) : P.pack_operand(cat, 3 * D, D, D);
-    L.Wo = x3 ? P.pair_w(P.eff_weight(lp + "attention.output.dense", D, D), D, D) : P.pack_operand(P.eff_weight(lp + "attention.output.dense", D, D), D, D, D);
+    L.Wo = x3 ? P.pair_w(P.eff_weight(lp + "attention.output.dense", D, D), D, D)
+         : f8 ? P.pack_fp8(P.eff_weight(lp + "attention.output.dense", D, D), D, D, &L.so)
+              : P.pack_operand(P.eff_weight(lp + "attention.output.dense", D, D), D, D, D);
     L.bo = P.eff_bias(lp + "attention.output.dense", D);
     if (c.swiglu) {
       L.W1 = x3 ? P.pair_w(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, D);
@@ -549,7 +551,12 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
       a.Lq = a.Lk = N; a.B = B; a.heads = g.heads; a.dh = D / g.heads; a.scale = scale;
       KCHK(h, launch_attn_f32(a, s));
     }
-    rc = linear(h, bf, ws.ctx, D, L.Wo, D, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;   // K6
+    if (f8) {   // out-proj on e4m3 operands too: the bf16 context rows are quantised by one pass (the attention kernel writes them head-wise)
+      KCHK(h, launch_quant_rows_fp8(ws.ctx, 1, D, M, D, (unsigned char*)ws.y, D, ws.rs, s));
+      rc = linear8(h, ws.y, ws.rs, L.Wo, L.so, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;
+    } else {
+      rc = linear(h, bf, ws.ctx, D, L.Wo, D, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;   // K6
+    }
     if (f8) {
       { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, (unsigned char*)ws.y, ws.rs)); }
       if (g.swiglu) {

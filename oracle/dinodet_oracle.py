@@ -184,7 +184,7 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
         a = bb.lora_alpha
         # K3-K6   modeling_dinov2.py:361-370
         y = _layernorm(h, sd(lp + "norm1.weight"), sd(lp + "norm1.bias"), bb.ln_eps)
-        f8 = emu == "fp8"   # fp8 mode: QKV / MLP-in (/ SwiGLU MLP-out) linears on e4m3 operands, the rest as the bf16 mode
+        f8 = emu == "fp8"   # fp8 mode: QKV / out-proj / MLP-in (/ SwiGLU MLP-out) linears on e4m3 operands, the rest as the bf16 mode
         q = _maybe_lora_linear(sd, lp + "attention.attention.query", y, a, emu, f8)
         k = _maybe_lora_linear(sd, lp + "attention.attention.key", y, a, emu, f8)
         v = _maybe_lora_linear(sd, lp + "attention.attention.value", y, a, emu, f8)
@@ -203,7 +203,9 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
         else:
             ctx = torch.softmax(s, dim=-1) @ v
         ctx = ctx.transpose(1, 2).reshape(B, N, D)
-        o = _maybe_lora_linear(sd, lp + "attention.output.dense", ctx, a, emu)
+        if emu == "fp8":
+            ctx = _bf(ctx)            # the fp8 path stores the context in bf16, then quantises its rows
+        o = _maybe_lora_linear(sd, lp + "attention.output.dense", ctx, a, emu, emu == "fp8")
         h = o * sd(lp + "layer_scale1.lambda1") + h
         if taps is not None and i == 0:
             taps["block0_attn"] = h.clone()
