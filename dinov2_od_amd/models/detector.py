@@ -58,13 +58,13 @@ class DINOv2ObjectDetector(nn.Module, _EngineMixin):
     def forward_packed(self, pixel_values):
         """[B,3,H,W] -> packed detections [B, Q, C+4] (logits | boxes): the buffer the multi-GPU
         all-gather moves (dinov2_od_amd.dist.gather_detections)."""
-        if self._use_autograd():
+        if self._use_autograd(pixel_values):
             o = self.forward(pixel_values)
             return torch.cat([o["pred_logits"], o["pred_boxes"]], dim=-1)
         return self._get_engine().forward(pixel_values, self._engine_named())
 
     def forward(self, pixel_values):
         """pixel_values [batch, 3, H, W] -> {"pred_logits", "pred_boxes"} (detector.py:58-69)."""
-        if self._use_autograd():            # train(): autograd composite of the same math (detector.py:58-69)
+        if self._use_autograd(pixel_values):            # train(): autograd composite of the same math (detector.py:58-69)
             return self.decoder(self.backbone(pixel_values))
         return split_detections(self.forward_packed(pixel_values), self._dc_cfg.num_classes)

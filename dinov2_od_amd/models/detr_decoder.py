@@ -99,7 +99,7 @@ class DETRDecoder(nn.Module, _EngineMixin):
 
     def forward(self, src):
         """src [batch, seq_len, hidden_dim] -> {"pred_logits": [B,Q,C], "pred_boxes": [B,Q,4]}"""
-        if self._use_autograd():
+        if self._use_autograd(src):
             from . import _autograd
             return _autograd.decoder_forward(self, src)
         det = self._get_engine().decoder_forward(src, self._engine_named())

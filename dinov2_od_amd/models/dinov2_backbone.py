@@ -7,6 +7,8 @@ arithmetic runs in hand-written gfx950 kernels behind libdinodet.so (dinov2_od_a
 The HF `Dinov2Model` the reference wraps (dinov2_backbone.py:11) is mirrored structurally
 (embeddings / encoder.layer[i] / layernorm) without importing `transformers`.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -124,9 +126,13 @@ class _EngineMixin:
             self.__dict__["_engine"] = eng
         return eng
 
-    def _use_autograd(self):
+    def _use_autograd(self, x=None):
         """train() mode -> the autograd composite (models/_autograd.py): the native kernels have no backward yet
-        (SURVEY.md section 8f-1).  eval() mode is always native."""
+        (SURVEY.md section 8f-1).  eval() mode is always native.  Like the native path the composite is GPU-only: a CPU
+        tensor raises (DINODET_COMPOSITE_ON_CPU=1 lifts that for the CPU test-suite, which pins the composite against the
+        reference goldens)."""
+        if self.training and x is not None and not x.is_cuda and os.environ.get("DINODET_COMPOSITE_ON_CPU") != "1":
+            raise RuntimeError("inputs must be on the GPU: the MI355X path has no CPU fallback (train() mode included)")
         return self.training
 
     def set_precision(self, precision):
@@ -170,7 +176,7 @@ class DINOv2Backbone(nn.Module, _EngineMixin):
 
     def forward(self, pixel_values):
         """-> features [batch, seq_len, hidden_dim] fp32, CLS token at index 0 (dinov2_backbone.py:58-67)"""
-        if self._use_autograd():
+        if self._use_autograd(pixel_values):
             from . import _autograd
             return _autograd.backbone_forward(self, pixel_values)
         return self._get_engine().backbone_forward(pixel_values, self._engine_named())

@@ -103,6 +103,6 @@ def test_forward_without_gpu_fails_loudly():
         m(torch.zeros(1, 3, 224, 224))
     with pytest.raises(ValueError, match="channel dimension"):
         m(torch.zeros(1, 4, 224, 224))
-    m.train()                      # train(): the autograd composite, runs anywhere torch runs
-    o = m(torch.zeros(1, 3, 224, 224))
-    assert o["pred_logits"].requires_grad
+    m.train()                      # train(): the autograd composite is GPU-only too
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 224, 224))

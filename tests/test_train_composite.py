@@ -12,6 +12,12 @@ from tests import cases
 from tests.cases import rel_err
 
 
+@pytest.fixture(autouse=True)
+def _composite_on_cpu(monkeypatch):
+    """the composite is GPU-only in the product (no CPU fallback); the CPU suite lifts that to pin it against the goldens"""
+    monkeypatch.setenv("DINODET_COMPOSITE_ON_CPU", "1")
+
+
 def _detector(Q, dropout):
     bb, dc = cases.cfg1(Q)
     m = DINOv2ObjectDetector(num_classes=91, dino_model_name="facebook/dinov2-small", lora_r=1, lora_alpha=1.0, hidden_dim=256,
@@ -67,6 +73,13 @@ def test_gradients_reach_exactly_the_trainable_subset():
     v0 = p._version
     torch.optim.SGD([q for q in m.parameters() if q.requires_grad], lr=0.1).step()
     assert p._version > v0
+
+
+def test_composite_refuses_cpu_tensors_without_the_test_switch(monkeypatch):
+    monkeypatch.delenv("DINODET_COMPOSITE_ON_CPU")
+    m = _detector(25, 0.0).train()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 70, 70))
 
 
 def test_dropout_is_active_in_train_mode_only():
