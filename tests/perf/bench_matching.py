@@ -2,7 +2,7 @@
 """Matcher cost matrices on device (dod_match_cost) vs the torch-CPU restatement of matching.py:79-98, bench workload's
 shapes (B=64, Q=100, C=91, 0..30 targets per image)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from dinov2_od_amd import matching as mt, synth
 from oracle import matching_oracle as mo

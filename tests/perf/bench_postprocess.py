@@ -3,7 +3,7 @@
 (B=64, Q=100, C=91).  Prints kernel time (HIP events, detections resident in HBM), end-to-end time incl. the record
 copy to the host, and the numpy oracle's time for the same input."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from dinov2_od_amd import _native as nat, postprocess as pp, synth
 from oracle import postprocess_oracle as ppo
