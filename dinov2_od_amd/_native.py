@@ -47,6 +47,7 @@ SYMBOLS = {
     "dod_num_tokens": (_I, [_P, _I, _I]),
     "dod_forward": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "dod_backbone_forward": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
+    "dod_backbone_prefix": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     "dod_decoder_forward": (_I, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
     "dod_decoder_workspace_bytes": (_SZ, [_P, _I, _I]),
     "dod_set_tap": (_I, [_P, _I, _P]),

@@ -468,7 +468,9 @@ GemmEpi epi(const float* bias, float* of32, void* obf, int ldc, int act = ACT_NO
 }
 
 // DINOv2Backbone.forward (dinov2_backbone.py:58-67) -> ws.mem (operand dtype) and/or feat_f32
-int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const BbWS& ws, float* feat_f32, bool want_mem, hipStream_t s) {
+// stop_blocks >= 0: run the embeddings and the first stop_blocks encoder blocks only and copy the fp32 residual stream to x_out
+int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const BbWS& ws, float* feat_f32, bool want_mem, hipStream_t s,
+                  int stop_blocks = -1, float* x_out = nullptr) {
   const dod_config& g = h->cfg;
   const bool bf = is_bf16(h);
   const int D = g.hidden, F = g.ffn_hidden, p = g.patch;
@@ -498,7 +500,8 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   float* yf = bf ? nullptr : (float*)ws.y; bf16_t* yb = bf ? (bf16_t*)ws.y : nullptr;
   const bool f8 = is_fp8(h);   // LayerNorm / SwiGLU emit e4m3 rows + per-row scales (ws.rs) for the QKV / MLP linears
   const bool x3 = is_x3(h);
-  for (int i = 0; i < g.layers; ++i) {
+  const int nblocks = stop_blocks >= 0 ? (stop_blocks < g.layers ? stop_blocks : g.layers) : g.layers;
+  for (int i = 0; i < nblocks; ++i) {
     const BLayer& L = h->L[i];
     if (x3) {   // bf16x3: every block linear as a split product on the bf16 kernels; attention and LayerNorm in fp32
       bf16_t* y3 = (bf16_t*)ws.y;
@@ -580,6 +583,10 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
       rc = linear(h, bf, ws.hbuf, F, L.W2, F, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
     }
     tap(h, 1 + i, ws.x, false, (size_t)M * D, s);
+  }
+  if (stop_blocks >= 0) {
+    HIPCHK(h, hipMemcpyAsync(x_out, ws.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+    return DOD_OK;
   }
   // final LayerNorm (+ projection K9)
   if (!g.target_dim) {
@@ -884,6 +891,19 @@ int dod_backbone_forward(dod_handle* h, const float* pixels, int B, int H, int W
   BbWS bw;
   carve_backbone(h, c, B, N, &bw);
   return backbone_impl(h, pixels, B, H, W, bw, features, false, (hipStream_t)stream);
+}
+
+int dod_backbone_prefix(dod_handle* h, const float* pixels, int B, int H, int W, int nblocks, float* x_out, void* workspace, size_t wsb, void* stream) {
+  int rc;
+  if (!check_common(h, B, H, W, &rc)) return rc;
+  if (!pixels || !x_out || !workspace) return fail(h, DOD_ERR_INVALID, "null buffer");
+  if (nblocks < 0 || nblocks > h->cfg.layers) return fail(h, DOD_ERR_INVALID, "nblocks %d outside 0..%d", nblocks, h->cfg.layers);
+  if (wsb < dod_workspace_bytes(h, B, H, W)) return fail(h, DOD_ERR_STATE, "workspace too small: %zu < %zu", wsb, dod_workspace_bytes(h, B, H, W));
+  const int N = dod_num_tokens(h, H, W);
+  Carver c(align_ws(workspace));
+  BbWS bw;
+  carve_backbone(h, c, B, N, &bw);
+  return backbone_impl(h, pixels, B, H, W, bw, nullptr, false, (hipStream_t)stream, nblocks, x_out);
 }
 
 int dod_decoder_forward(dod_handle* h, const float* memory, int B, int N, float* det, void* workspace, size_t wsb, void* stream) {

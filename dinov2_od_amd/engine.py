@@ -152,6 +152,21 @@ class Engine:
                                                  ws.numel(), nat.stream_ptr()), self._h)
         return feats
 
+    def backbone_prefix(self, pixel_values, named, nblocks):
+        """embeddings + the first `nblocks` encoder blocks -> fp32 residual stream [B, N, hidden] (no autograd)"""
+        x = self._check_pixels(pixel_values)
+        self.sync_weights(named)
+        B, _, H, W = x.shape
+        nbytes = self._lib.dod_workspace_bytes(self._h, B, H, W)
+        if nbytes == 0:
+            raise ValueError(f"unsupported input {tuple(x.shape)}")
+        ws = self._workspace(nbytes, x.device)
+        N = self._lib.dod_num_tokens(self._h, H, W)
+        out = torch.empty(B, N, self.bb.hidden, dtype=torch.float32, device=x.device)
+        nat.check(self._lib.dod_backbone_prefix(self._h, nat.ptr(x), B, H, W, int(nblocks), nat.ptr(out), nat.ptr(ws), ws.numel(),
+                                                nat.stream_ptr()), self._h)
+        return out
+
     def decoder_forward(self, memory, named):
         if memory.dim() != 3 or memory.shape[-1] != self.dc.hidden_dim:
             raise ValueError(f"src must be [batch, seq_len, {self.dc.hidden_dim}], got {tuple(memory.shape)}")

@@ -6,6 +6,8 @@ The native HIP path is inference-only (no backward kernels yet).  So that the re
 reference trains (LoRA A/B, projection, decoder, heads; the DINOv2 weights stay frozen, dinov2_backbone.py:40-41) -- with the
 reference's dropout placement (deformable_attention.py:195-209, 235, 261, 265-266).  `eval()` mode always runs the native
 kernels; after an optimizer step the engine re-packs the changed weights automatically (engine.sync_weights).
+On the GPU the frozen prefix of the backbone (embeddings + every block before the first LoRA-adapted one: 10 of ViT-B's 12)
+runs in the native kernels; only the adapted blocks, the projection and the decoder are evaluated here.
 This file is the stop-gap the survey describes, not the measured hot path.
 """
 import torch
@@ -42,10 +44,20 @@ def backbone_forward(m, pixel_values):
     if Cc != 3:
         raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the "
                          f"configuration. Expected 3 but got {Cc}.")
-    x = emb.patch_embeddings.projection(pixel_values.float()).flatten(2).transpose(1, 2)      # :141-149
-    h = torch.cat((emb.cls_token.expand(B, -1, -1), x), dim=1) + _pos_embed(emb.position_embeddings, bb.patch, H, W)
+    layers = list(dino.encoder.layer)
+    # The DINOv2 weights are frozen and only the last blocks carry LoRA adapters (dinov2_backbone.py:40-51): every block before
+    # the first adapted one needs no autograd, so on the GPU that prefix runs in the native kernels (dod_backbone_prefix).
+    first_trainable = next((i for i, L in enumerate(layers) if any(p.requires_grad for p in L.parameters())), len(layers))
+    frozen_front = not any(p.requires_grad for p in emb.parameters())
+    if pixel_values.is_cuda and frozen_front and first_trainable > 0 and not pixel_values.requires_grad:
+        with torch.no_grad():
+            h = m._get_engine().backbone_prefix(pixel_values, m._engine_named(), first_trainable)
+        layers = layers[first_trainable:]
+    else:
+        x = emb.patch_embeddings.projection(pixel_values.float()).flatten(2).transpose(1, 2)      # :141-149
+        h = torch.cat((emb.cls_token.expand(B, -1, -1), x), dim=1) + _pos_embed(emb.position_embeddings, bb.patch, H, W)
     nh = bb.heads
-    for L in dino.encoder.layer:                                                             # :361-380
+    for L in layers:                                                                         # :361-380
         y = L.norm1(h)
         a = L.attention.attention
         N = y.shape[1]

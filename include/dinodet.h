@@ -110,6 +110,11 @@ int dod_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* 
 /* DINOv2Backbone.forward: pixels -> features [B, N, out_dim] fp32 (CLS token at index 0). */
 int dod_backbone_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* features,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The frozen prefix of the backbone: embeddings (modeling_dinov2.py:97-116) and the first `nblocks` encoder blocks
+ * (:361-380) -> the fp32 residual stream x_out [B, N, hidden].  Training only touches the last two blocks (LoRA,
+ * dinov2_backbone.py:47-51), so the blocks before them need no autograd: the train()-mode composite runs them here. */
+int dod_backbone_prefix(dod_handle* h, const float* pixels, int B, int H, int W, int nblocks, float* x_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* DETRDecoder.forward: memory [B, N, Dd] fp32 -> detections [B, Q, C+4] packed. */
 int dod_decoder_forward(dod_handle* h, const float* memory, int B, int N, float* detections,

@@ -233,6 +233,37 @@ def test_train_step_then_native_eval(G):
     assert rel_err(comp["pred_logits"].cpu().numpy(), after[..., :91].cpu().numpy()) < TOL
 
 
+def test_train_forward_runs_the_frozen_prefix_natively(G):
+    """train() on the GPU: embeddings + the blocks before the first LoRA-adapted one come from dod_backbone_prefix (no autograd
+    needed there), the rest from the autograd composite -- same outputs and same gradients as the all-composite evaluation
+    (selected here by an input that requires grad)."""
+    bb, dc = cases.cfg1(25)
+    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-small")
+    m.train()
+    m._dropout_p = m.decoder._dropout_p = 0.0
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    x = G.to_gpu(synth.make_pixels(2, 224, 224, seed=0))
+    eng = m.backbone._get_engine()
+    pre = eng.backbone_prefix(x, m.backbone._engine_named(), bb.layers - 2)
+    assert pre.shape == (2, num_tokens(224, 224), bb.hidden) and not pre.requires_grad
+
+    def run(inp):
+        m.zero_grad(set_to_none=True)
+        o = m(inp)
+        (o["pred_logits"].square().mean() + o["pred_boxes"].mean()).backward()
+        g = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        return o["pred_logits"].detach().clone(), g
+
+    hybrid, gh = run(x)
+    full, gf = run(x.clone().requires_grad_(True))
+    assert rel_err(hybrid.cpu().numpy(), full.cpu().numpy()) < 1e-4
+    assert set(gh) == set(gf) and any("lora_A" in k for k in gh)
+    for k in gh:
+        assert rel_err(gh[k].cpu().numpy(), gf[k].cpu().numpy()) < 2e-3, k
+
+
 def test_hipgraph_replay_matches_eager_and_tracks_weight_updates(G):
     """model.enable_hipgraph(): one captured graph per input shape, bit-identical to the eager launches, re-captured after a
     weight update (the packed weights move), several shapes side by side."""

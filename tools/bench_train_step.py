@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""train()-mode step (forward + backward) on the drop-in detector: native frozen prefix + autograd composite ("hybrid")
+vs the all-composite evaluation (selected by an input that requires grad).  ViT-B/14 224x224, batch 16."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import build
+m, bb, dc = build("facebook/dinov2-base", 100, os.environ.get("DINODET_PRECISION", "bf16"), torch.device("cuda"))
+m.train()
+x = torch.rand(16, 3, 224, 224, device="cuda")
+def step(inp):
+    m.zero_grad(set_to_none=True)
+    o = m(inp)
+    (o["pred_logits"].square().mean() + o["pred_boxes"].mean()).backward()
+for name, mk in (("hybrid (native prefix)", lambda: x), ("all-composite", lambda: x.clone().requires_grad_(True))):
+    for _ in range(2): step(mk())
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5): step(mk())
+    torch.cuda.synchronize()
+    print(f"{name:24s}: {(time.perf_counter() - t) / 5 * 1e3:7.1f} ms per forward+backward (batch 16, 224x224)")
