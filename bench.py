@@ -113,8 +113,8 @@ def oracle_error(gpu_det, oracle_out, C):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="vitb518", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3"])
@@ -188,14 +188,19 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # per-step spread (median, p10/p90)
         t0 = time.perf_counter()
-        for _ in range(a.steps):
+        evs[0].record()
+        for i in range(a.steps):
             run()
+            evs[i + 1].record()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
+        pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -240,6 +245,7 @@ def main():
            "config": {"workload": desc, "global_batch": global_batch, "per_gpu_batch": B_local, "image": R, "queries": Q,
                       "parallelism": f"dp{world}", "hipgraph": bool(use_graph),
                       "gflop_per_image": fpi / 1e9},
+           "step_ms_p10_p50_p90": [pct(0.10), pct(0.50), pct(0.90)],
            "mfma_roofline_frac_end_to_end": ips * fpi / (peak * world),
            "roofline": roof}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
