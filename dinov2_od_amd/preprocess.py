@@ -12,6 +12,19 @@ import torch
 from . import _native as nat
 
 
+_STAGE = None
+_STAGE_BUSY = None      # event recorded after the last async copy out of the staging buffer
+
+
+def _staging(nbytes):
+    global _STAGE
+    if _STAGE_BUSY is not None:
+        _STAGE_BUSY.synchronize()          # the previous batch's DMA must have left the buffer before it is refilled
+    if _STAGE is None or _STAGE.numel() < nbytes:
+        _STAGE = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+    return _STAGE
+
+
 def preprocess_batch(images, size=(224, 224), device="cuda"):
     """images: sequence of uint8 RGB images [H_i, W_i, 3] (numpy arrays, torch tensors or PIL images); size: (height, width)
     as torchvision's Resize takes it.  Returns float32 [B, 3, height, width] on `device`."""
@@ -32,7 +45,16 @@ def preprocess_batch(images, size=(224, 224), device="cuda"):
     tsz = hs.astype(np.int64) * out_w * 3
     tmp_offs = np.concatenate([[0], np.cumsum(tsz)[:-1]]).astype(np.int64)
     dev = torch.device(device)
-    src = torch.from_numpy(np.concatenate([a.reshape(-1) for a in arrs])).to(dev)       # one H2D copy of the raw bytes
+    # the raw bytes are gathered straight into a (cached) pinned staging buffer: one host copy, one DMA to the device
+    total = int(sizes.sum())
+    stage = _staging(total)
+    sv = stage.numpy()
+    for a, o in zip(arrs, src_offs):
+        sv[o:o + a.size] = a.reshape(-1)
+    src = stage[:total].to(dev, non_blocking=True)
+    global _STAGE_BUSY
+    _STAGE_BUSY = torch.cuda.Event()
+    _STAGE_BUSY.record()
     meta = [torch.from_numpy(x).to(dev) for x in (src_offs, hs, ws, tmp_offs)]
     tmp = torch.empty(int(tsz.sum()), dtype=torch.uint8, device=dev)
     out = torch.empty(B, 3, out_h, out_w, dtype=torch.float32, device=dev)
