@@ -10,6 +10,8 @@ On the GPU the frozen prefix of the backbone (embeddings + every block before th
 runs in the native kernels; only the adapted blocks, the projection and the decoder are evaluated here.
 This file is the stop-gap the survey describes, not the measured hot path.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -49,7 +51,8 @@ def backbone_forward(m, pixel_values):
     # the first adapted one needs no autograd, so on the GPU that prefix runs in the native kernels (dod_backbone_prefix).
     first_trainable = next((i for i, L in enumerate(layers) if any(p.requires_grad for p in L.parameters())), len(layers))
     frozen_front = not any(p.requires_grad for p in emb.parameters())
-    if pixel_values.is_cuda and frozen_front and first_trainable > 0 and not pixel_values.requires_grad:
+    if (pixel_values.is_cuda and frozen_front and first_trainable > 0 and not pixel_values.requires_grad
+            and os.environ.get("DINODET_COMPOSITE_FULL") != "1"):     # (=1: every block in torch, for A/B timing)
         with torch.no_grad():
             h = m._get_engine().backbone_prefix(pixel_values, m._engine_named(), first_trainable)
         layers = layers[first_trainable:]
