@@ -145,7 +145,8 @@ def test_attention_bf16_forced_rescale(G):
 
 
 @pytest.mark.parametrize("B,Lq,Lk,heads,dh", [(2, 7, 7, 4, 32), (2, 100, 100, 8, 96), (1, 300, 300, 8, 96), (2, 5, 1370, 2, 96),
-                                             (1, 257, 257, 6, 64), (2, 33, 70, 3, 128), (1, 9, 17, 5, 48)])
+                                             (1, 257, 257, 6, 64), (2, 33, 70, 3, 128), (1, 9, 17, 5, 48),
+                                             (1, 1370, 1370, 2, 64), (3, 130, 130, 2, 64), (2, 17, 17, 2, 64), (2, 5, 200, 1, 64)])
 def test_attention_f32(G, B, Lq, Lk, heads, dh):
     E = heads * dh
     q, k, v = _n("g.q", (B, Lq, E)), _n("g.k", (B, Lk, E)), _n("g.v", (B, Lk, E))
