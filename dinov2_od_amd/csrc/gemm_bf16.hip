@@ -836,6 +836,15 @@ __global__ __launch_bounds__(256, 2) void mfma_peak_kernel(int iters, unsigned l
   bf16x8 a, b;
 #pragma unroll
   for (int i = 0; i < 8; ++i) { a[i] = (bf16_t)(0x3c00 + threadIdx.x + i); b[i] = (bf16_t)(0x3c10 + threadIdx.x * 3 + i); }
+  if (iters < 0) {   // negative iteration count: random sign / mantissa operands (+-0.5..1): the datapath toggles as on real data
+    iters = -iters;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned r1 = (threadIdx.x * 8u + i + 1u) * 2654435761u, r2 = (threadIdx.x * 8u + i + 7u) * 40503u * 2246822519u;
+      a[i] = (bf16_t)(0x3f00u | ((r1 >> 9) & 0xffu) | (((r1 >> 20) & 1u) << 15));
+      b[i] = (bf16_t)(0x3f00u | ((r2 >> 9) & 0xffu) | (((r2 >> 20) & 1u) << 15));
+    }
+  }
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   float chk = 0.f;
   if (SHAPE == 16) {
@@ -854,7 +863,7 @@ __global__ __launch_bounds__(256, 2) void mfma_peak_kernel(int iters, unsigned l
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    const float fa = 1.0f + 0.001f * threadIdx.x, fb = 0.5f + 0.002f * threadIdx.x;
+    const float fa = bf2f(a[0]) * (1.0f + 0.37f * bf2f(a[1])), fb = bf2f(b[0]) * (1.0f + 0.41f * bf2f(b[1]));
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[i], 0, 0, 0);
@@ -882,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void mfma_peak_kernel(int iters, unsigned l
   }
 }
 extern "C" int dod_debug_mfma_peak(int shape, int iters, int blocks, void* dev_out, void* stream) {
-  if (!dev_out || iters <= 0 || blocks <= 0 || (shape != 16 && shape != 32 && shape != 2)) return 1;
+  if (!dev_out || iters == 0 || blocks <= 0 || (shape != 16 && shape != 32 && shape != 2)) return 1;
   if (shape == 2) hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)dev_out);
   else if (shape == 16) hipLaunchKernelGGL(mfma_peak_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)dev_out);
   else hipLaunchKernelGGL(mfma_peak_kernel<32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)dev_out);

@@ -9,8 +9,8 @@ from dinov2_od_amd import _native as nat
 L = nat.lib()
 dev = torch.device("cuda:0")
 for shape, chains, flop in ((16, 8, 2 * 16 * 16 * 32), (32, 4, 2 * 32 * 32 * 16), (2, 4, 2 * 32 * 32 * 2)):   # shape 2 = v_mfma_f32_32x32x2_f32
-    for wg_per_cu in (1, 2, 4):
-        blocks, iters = 256 * wg_per_cu, 20000
+    for wg_per_cu, rnd in ((1, 0), (2, 0), (4, 0), (4, 1)):
+        blocks, iters = 256 * wg_per_cu, (-20000 if rnd else 20000)
         out = torch.zeros(blocks * 4, dtype=torch.int64, device=dev)
         for _ in range(2):
             nat.check(L.dod_debug_mfma_peak(shape, iters, blocks, nat.ptr(out), nat.stream_ptr()))
@@ -23,8 +23,9 @@ for shape, chains, flop in ((16, 8, 2 * 16 * 16 * 32), (32, 4, 2 * 32 * 32 * 16)
         t = a.elapsed_time(b) * 1e-3
         o = out.view(blocks, 4).cpu().double()
         cyc, ticks = o[:, 0].median().item(), o[:, 1].median().item()
+        iters = abs(iters)
         total = float(blocks) * 4 * iters * chains * flop
-        print(f"mfma {shape}: {wg_per_cu} WG/CU ({wg_per_cu} waves/SIMD): {total / t / 1e12:7.1f} TFLOP/s wall; "
+        print(f"mfma {shape}{' random operands' if rnd else ''}: {wg_per_cu} WG/CU ({wg_per_cu} waves/SIMD): {total / t / 1e12:7.1f} TFLOP/s wall; "
               f"s_memtime {cyc / (ticks / 100e6) / 1e9:5.2f} G counts/s; {cyc / (iters * chains):6.2f} counts per MFMA per wave")
 
 print("MFMA / VALU co-issue probe (4 x 32x32x16 MFMA = 128 MFMA cycles per iteration; v_fma_f32 = 4 issue cycles each):")
