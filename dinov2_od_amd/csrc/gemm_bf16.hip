@@ -857,6 +857,16 @@ __global__ __launch_bounds__(256, 2) void mfma_peak_kernel(int iters, unsigned l
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) chk += acc[i][0];
+  } else if (SHAPE == 1) {   // v_mfma_f32_32x32x2_f32, ONE dependent chain per wave (what a single-accumulator kernel issues)
+    f32x16 acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+    const float fa = bf2f(a[0]) * (1.0f + 0.37f * bf2f(a[1])), fb = bf2f(b[0]) * (1.0f + 0.41f * bf2f(b[1]));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc1, 0, 0, 0);
+    }
+    chk += acc1[0];
   } else if (SHAPE == 2) {   // v_mfma_f32_32x32x2_f32 (exact fp32), 4 chains
     f32x16 acc[4];
 #pragma unroll
@@ -891,8 +901,9 @@ __global__ __launch_bounds__(256, 2) void mfma_peak_kernel(int iters, unsigned l
   }
 }
 extern "C" int dod_debug_mfma_peak(int shape, int iters, int blocks, void* dev_out, void* stream) {
-  if (!dev_out || iters == 0 || blocks <= 0 || (shape != 16 && shape != 32 && shape != 2)) return 1;
-  if (shape == 2) hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)dev_out);
+  if (!dev_out || iters == 0 || blocks <= 0 || (shape != 16 && shape != 32 && shape != 2 && shape != 1)) return 1;
+  if (shape == 1) hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)dev_out);
+  else if (shape == 2) hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)dev_out);
   else if (shape == 16) hipLaunchKernelGGL(mfma_peak_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)dev_out);
   else hipLaunchKernelGGL(mfma_peak_kernel<32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, (unsigned long long*)dev_out);
   return hipGetLastError() == hipSuccess ? 0 : 4;

@@ -225,7 +225,7 @@ int dod_match_cost(const float* det, int B, int Q, int C, const int64_t* labels,
 int dod_debug_gemm_stamps(void* dev_buf);
 /* same for the bf16 attention kernel: {shader cycles in the tile loop, cycles waiting for DMA + barrier, tiles, active} */
 int dod_debug_attn_stamps(void* dev_buf);
-/* register-only MFMA loop (shape 16: v_mfma_f32_16x16x32_bf16 x 8 chains, 32: 32x32x16 x 4 chains, 2: v_mfma_f32_32x32x2_f32 x 4 chains), `blocks` workgroups of
+/* register-only MFMA loop (shape 16: v_mfma_f32_16x16x32_bf16 x 8 chains, 32: 32x32x16 x 4 chains, 2: v_mfma_f32_32x32x2_f32 x 4 chains, 1: the same as one dependent chain; iters < 0: random operands), `blocks` workgroups of
  * 4 waves, `iters` rounds; dev_out[block*4 + {0,1}] = {shader cycles, 100-MHz ticks}.  Measures the SUSTAINED matrix rate and
  * clock of the part under MFMA load (tools/mfma_peak.py); not used by the forward. */
 int dod_debug_mfma_peak(int shape, int iters, int blocks, void* dev_out, void* stream);

@@ -8,7 +8,7 @@ from dinov2_od_amd import _native as nat
 
 L = nat.lib()
 dev = torch.device("cuda:0")
-for shape, chains, flop in ((16, 8, 2 * 16 * 16 * 32), (32, 4, 2 * 32 * 32 * 16), (2, 4, 2 * 32 * 32 * 2)):   # shape 2 = v_mfma_f32_32x32x2_f32
+for shape, chains, flop in ((16, 8, 2 * 16 * 16 * 32), (32, 4, 2 * 32 * 32 * 16), (2, 4, 2 * 32 * 32 * 2), (1, 4, 2 * 32 * 32 * 2)):   # shape 2 = v_mfma_f32_32x32x2_f32 (4 chains), 1 = the same, one dependent chain
     for wg_per_cu, rnd in ((1, 0), (2, 0), (4, 0), (4, 1)):
         blocks, iters = 256 * wg_per_cu, (-20000 if rnd else 20000)
         out = torch.zeros(blocks * 4, dtype=torch.int64, device=dev)
