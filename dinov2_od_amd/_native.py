@@ -40,7 +40,7 @@ SYMBOLS = {
     "dod_create": (_I, [C.POINTER(DodConfig), C.POINTER(_P)]),
     "dod_destroy": (None, [_P]),
     "dod_last_error": (C.c_char_p, [_P]),
-    "dod_set_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "dod_set_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I, _I]),
     "dod_finalize_weights": (_I, [_P, _P]),
     "dod_prepare": (_I, [_P, _I, _I, _P]),
     "dod_workspace_bytes": (_SZ, [_P, _I, _I, _I]),

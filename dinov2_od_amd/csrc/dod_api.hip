@@ -16,7 +16,8 @@ int launch_widen_bf16(const bf16_t* in, float* out, size_t n, hipStream_t s);   
 
 namespace {
 
-struct WRef { const float* ptr; std::vector<int64_t> shape; size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; } };
+// ptr: the fp32 view the packer reads (== raw for fp32 tensors; a widened temporary made by finalize for bf16 ones)
+struct WRef { const float* ptr; std::vector<int64_t> shape; const void* raw = nullptr; int dtype = DOD_F32; size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; } };
 
 struct BLayer {
   void *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;   // bf16 or fp32 by precision (fp8 mode: Wqkv, W1 and the SwiGLU W2 are e4m3)
@@ -61,7 +62,10 @@ struct dod_handle {
   float *query = nullptr, *cls_w = nullptr, *cls_b = nullptr, *bb0_w = nullptr, *bb0_b = nullptr, *bb2_w = nullptr, *bb2_b = nullptr;
   int ncat = 0;
   // position-table cache
-  int pos_H = -1, pos_W = -1; float* pos_hw = nullptr; size_t pos_hw_elems = 0;
+  // one table per distinct (H, W), kept until the next finalize / destroy: alternating input sizes neither leak nor
+  // re-allocate, and hipGraphs captured for an earlier shape keep valid pointers
+  std::map<std::pair<int, int>, float*> pos_cache;
+  int pos_H = -1, pos_W = -1; float* pos_hw = nullptr;
   std::map<int, float*> taps;
   // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
   bool prof_on = false;
@@ -218,9 +222,26 @@ struct Packer {
 int finalize_impl(dod_handle* h, hipStream_t s) {
   for (void* p : h->owned) (void)hipFree(p);
   h->owned.clear(); h->L.clear(); h->DL.clear(); h->finalized = false;
-  h->pos_H = h->pos_W = -1; h->pos_hw = nullptr; h->pos_hw_elems = 0;
+  h->pos_H = h->pos_W = -1; h->pos_hw = nullptr; h->pos_cache.clear();
   const dod_config& c = h->cfg;
   Packer P{h, s};
+  {   // bf16 tensors (dod_set_weight dtype DOD_BF16): widen once per distinct storage so that tied parameters stay tied
+    std::map<const void*, float*> widened;
+    for (auto& kv : h->w) {
+      WRef& r = kv.second;
+      if (r.dtype == DOD_F32) { r.ptr = (const float*)r.raw; continue; }
+      auto it = widened.find(r.raw);
+      if (it == widened.end()) {
+        float* f = P.alloc<float>(r.numel(), true);
+        if (!f || launch_widen_bf16((const bf16_t*)r.raw, f, r.numel(), s)) {
+          for (void* t : P.tmp) (void)hipFree(t);
+          return P.rc ? P.rc : fail(h, DOD_ERR_HIP, "widening of a bf16 weight failed");
+        }
+        it = widened.emplace(r.raw, f).first;
+      }
+      r.ptr = it->second;
+    }
+  }
   const int D = c.hidden, F = c.ffn_hidden, G = c.pos_grid, p = c.patch;
   const std::string bb = "backbone.dino.", e = bb + "embeddings.";
   h->has_bb = h->has_dec = false;
@@ -427,20 +448,30 @@ int prepare_impl(dod_handle* h, int H, int W, hipStream_t s) {
   const int gh = H / g.patch, gw = W / g.patch;
   // modeling_dinov2.py:71-72: used as is only when num_patches == num_positions and H == W
   if (gh * gw == g.pos_grid * g.pos_grid && H == W) { h->pos_hw = h->pos; h->pos_H = H; h->pos_W = W; return DOD_OK; }
-  const size_t need = (size_t)(gh * gw + 1) * g.hidden;
-  float* buf = nullptr;
-  HIPCHK(h, hipMalloc((void**)&buf, need * 4));
-  h->owned.push_back(buf);
-  KCHK(h, launch_pos_resize(h->pos, g.pos_grid, gh, gw, g.hidden, buf, s));
-  h->pos_hw = buf; h->pos_hw_elems = need; h->pos_H = H; h->pos_W = W;
+  // the table depends on (gh, gw) only -- and on H != W for the square-count case above
+  const std::pair<int, int> key(gh, gw);
+  auto it = h->pos_cache.find(key);
+  if (it == h->pos_cache.end()) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return fail(h, DOD_ERR_STATE, "first forward at %dx%d inside a stream capture: call dod_prepare(h, %d, %d) before capturing", H, W, H, W);
+    const size_t need = (size_t)(gh * gw + 1) * g.hidden;
+    float* buf = nullptr;
+    HIPCHK(h, hipMalloc((void**)&buf, need * 4));
+    h->owned.push_back(buf);
+    KCHK(h, launch_pos_resize(h->pos, g.pos_grid, gh, gw, g.hidden, buf, s));
+    it = h->pos_cache.emplace(key, buf).first;
+  }
+  h->pos_hw = it->second; h->pos_H = H; h->pos_W = W;
   return DOD_OK;
 }
 
 int tap(dod_handle* h, int stage, const void* src, bool src_bf16, size_t n, hipStream_t s);
 
 // generic linear on the precision's operand dtype
-int linear(dod_handle* h, bool bf, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
-  ProfScope ps(h, s, bf ? PC_GEMM_BF16 : PC_GEMM_F32, 2.0 * M * N * (e.rows_per_img > 0 ? 3.0 * h->cfg.patch * h->cfg.patch : (double)K));
+// flops_K: the ALGORITHMIC reduction length booked for the roofline (0 = K; the split-3 form executes 3K for K)
+int linear(dod_handle* h, bool bf, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s, int flops_K = 0) {
+  ProfScope ps(h, s, bf ? PC_GEMM_BF16 : PC_GEMM_F32, 2.0 * M * N * (e.rows_per_img > 0 ? 3.0 * h->cfg.patch * h->cfg.patch : (double)(flops_K ? flops_K : K)));
   int r = bf ? launch_gemm_bf16((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, e, s)
              : launch_gemm_f32((const float*)A, lda, (const float*)W, ldw, M, N, K, e, s);
   if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "linear launch rejected (M=%d N=%d K=%d bf16=%d rc=%d)", M, N, K, (int)bf, r);
@@ -644,7 +675,7 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
     static const int qrows = getenv("DINODET_QSPLIT_ROWS") ? atoi(getenv("DINODET_QSPLIT_ROWS")) : 1024;   // tuning
     if ((bf || x3) && W3 && ws.a3 && rows >= qrows && Nout >= 128 && Nout % 4 == 0 && e.ldc % 4 == 0 && e.act != ACT_SIGMOID) {
       KCHK(h, launch_split3(A, K, ws.a3, rows, K, 0, s));
-      return linear(h, true, ws.a3, 3 * K, W3, 3 * K, rows, Nout, 3 * K, e, s);
+      return linear(h, true, ws.a3, 3 * K, W3, 3 * K, rows, Nout, 3 * K, e, s, K);
     }
     return linear(h, false, A, K, Wf, K, rows, Nout, K, e, s);
   };
@@ -777,11 +808,12 @@ void dod_destroy(dod_handle* h) {
   delete h;
 }
 
-int dod_set_weight(dod_handle* h, const char* key, const void* dev_ptr, const int64_t* shape, int ndim) {
+int dod_set_weight(dod_handle* h, const char* key, const void* dev_ptr, const int64_t* shape, int ndim, int dtype) {
   if (!h || !key || !dev_ptr || ndim < 0 || ndim > 8 || (ndim && !shape)) return fail(h, DOD_ERR_INVALID, "dod_set_weight: bad argument");
+  if (dtype != DOD_F32 && dtype != DOD_BF16) return fail(h, DOD_ERR_INVALID, "dod_set_weight('%s'): dtype %d is neither DOD_F32 nor DOD_BF16", key, dtype);
   std::string k(key);
   if (k.rfind("module.", 0) == 0) k = k.substr(7);   // DDP prefix, train.py:700-709
-  WRef r; r.ptr = (const float*)dev_ptr; r.shape.assign(shape, shape + ndim);
+  WRef r; r.raw = dev_ptr; r.dtype = dtype; r.ptr = dtype == DOD_F32 ? (const float*)dev_ptr : nullptr; r.shape.assign(shape, shape + ndim);
   h->w[k] = r;
   h->finalized = false;
   return DOD_OK;

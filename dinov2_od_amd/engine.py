@@ -14,7 +14,10 @@ from .config import BackboneConfig, DecoderConfig
 
 
 def default_precision():
-    return os.environ.get("DINODET_PRECISION", "bf16")
+    """Default = the parity-gated mode on the bf16 matrix cores ("bf16x3": within 1e-3 of the reference's fp32 CPU
+    forward, tests/test_gpu_forward.py GATED).  "bf16" (single-pass bf16 operands: fastest, ~2e-2 from the reference on
+    logits) and "fp8" are opt-in throughput modes; "fp32" is the exact-fp32 mode."""
+    return os.environ.get("DINODET_PRECISION", "bf16x3")
 
 
 def make_config(bb: BackboneConfig, dc: DecoderConfig, precision: str) -> nat.DodConfig:
@@ -40,12 +43,13 @@ class Engine:
         nat.check(self._lib.dod_create(C.byref(cfg), C.byref(self._h)))
         self._sig = None
         self._ws = None
+        self._device = None  # the device the packed weights live on (set by sync_weights)
         self._keep = []     # tensors whose pointers the handle holds until finalize returns
         self._tap_bufs = {}
         # hipGraph replay of the whole forward, one captured graph per input shape (opt-in: DINODET_HIPGRAPH=1 or
         # model.enable_hipgraph()): ~100 launches per forward are launch-bound at small batch
         self.use_graph = os.environ.get("DINODET_HIPGRAPH", "0") == "1"
-        self._graphs = {}   # (B, H, W, device) -> (graph, static input, static output)
+        self._graphs = {}   # (shape, device) -> (graph, static input, static output, the workspace the graph was captured on)
 
     def close(self):
         if self._h:
@@ -70,25 +74,43 @@ class Engine:
         if sig == self._sig:
             return
         self._keep = []
-        for k, t in named:
-            if not t.is_cuda:
-                raise RuntimeError(f"parameter {k} is on {t.device}: the MI355X path has no CPU fallback")
-            if t.dtype != torch.float32 or not t.is_contiguous():
-                t = t.detach().to(torch.float32).contiguous()
-                self._keep.append(t)
-            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
-            nat.check(self._lib.dod_set_weight(self._h, k.encode(), nat.ptr(t), shape, t.dim()), self._h)
-        nat.check(self._lib.dod_finalize_weights(self._h, nat.stream_ptr()), self._h)
+        devs = {t.device for _, t in named}
+        if len(devs) != 1:
+            raise RuntimeError(f"parameters live on several devices ({sorted(map(str, devs))}): one replica per GPU")
+        dev = next(iter(devs))
+        if dev.type != "cuda":
+            raise RuntimeError(f"parameters are on {dev}: the MI355X path has no CPU fallback")
+        with torch.cuda.device(dev):        # hipMalloc of the packed copy and the pack kernels bind to the parameters' GPU
+            for k, t in named:
+                if t.dtype == torch.bfloat16 and t.is_contiguous():
+                    dt = nat.DOD_BF16
+                else:
+                    dt = nat.DOD_F32
+                    if t.dtype != torch.float32 or not t.is_contiguous():
+                        t = t.detach().to(torch.float32).contiguous()
+                        self._keep.append(t)
+                shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+                nat.check(self._lib.dod_set_weight(self._h, k.encode(), nat.ptr(t), shape, t.dim(), dt), self._h)
+            nat.check(self._lib.dod_finalize_weights(self._h, nat.stream_ptr()), self._h)
         self._keep = []
         self._sig = sig
+        self._device = dev
         self._ws = None
         self._graphs = {}       # packed weights were reallocated: captured graphs hold stale pointers
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, nbytes, device):
+        """the eager calls' scratch; captured graphs own theirs (a graph bakes the addresses in, so its workspace must
+        outlive every later, larger eager call)"""
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._ws
+
+    def _on_device(self, x):
+        """input and packed weights must share a GPU; the returned context makes that GPU current (streams, hipMalloc)"""
+        if self._device is not None and x.device != self._device:
+            raise RuntimeError(f"input is on {x.device} but the model's parameters are on {self._device}")
+        return torch.cuda.device(x.device)
 
     @staticmethod
     def _check_pixels(x):
@@ -108,24 +130,27 @@ class Engine:
         ent = self._graphs.get(key)
         if ent is None:
             xs = x.clone()
-            self._launch_forward(xs)                       # warm-up outside capture: position table, func attributes, workspace
+            B, _, H, W = x.shape
+            ws = torch.empty(self._lib.dod_workspace_bytes(self._h, B, H, W), dtype=torch.uint8, device=x.device)
+            self._launch_forward(xs, ws)                   # warm-up outside capture: position table, func attributes
             torch.cuda.synchronize(x.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                out = self._launch_forward(xs)
-            ent = (g, xs, out)
+                out = self._launch_forward(xs, ws)
+            ent = (g, xs, out, ws)
             self._graphs[key] = ent
-        g, xs, out = ent
+        g, xs, out, _ = ent
         xs.copy_(x)
         g.replay()
         return out
 
-    def _launch_forward(self, x):
+    def _launch_forward(self, x, ws=None):
         B, _, H, W = x.shape
         nbytes = self._lib.dod_workspace_bytes(self._h, B, H, W)
         if nbytes == 0:
             raise ValueError(f"unsupported input {tuple(x.shape)}")
-        ws = self._workspace(nbytes, x.device)
+        if ws is None:
+            ws = self._workspace(nbytes, x.device)
         det = torch.empty(B, self.dc.num_queries, self.dc.num_classes + 4, dtype=torch.float32, device=x.device)
         nat.check(self._lib.dod_forward(self._h, nat.ptr(x), B, H, W, nat.ptr(det), nat.ptr(ws), ws.numel(),
                                         nat.stream_ptr()), self._h)
@@ -134,9 +159,10 @@ class Engine:
     def forward(self, pixel_values, named):
         x = self._check_pixels(pixel_values)
         self.sync_weights(named)
-        if self.use_graph and not torch.cuda.is_current_stream_capturing() and not self._tap_bufs:
-            return self._forward_graph(x)
-        return self._launch_forward(x)
+        with self._on_device(x):
+            if self.use_graph and not torch.cuda.is_current_stream_capturing() and not self._tap_bufs:
+                return self._forward_graph(x)
+            return self._launch_forward(x)
 
     def backbone_forward(self, pixel_values, named):
         x = self._check_pixels(pixel_values)
@@ -145,11 +171,12 @@ class Engine:
         nbytes = self._lib.dod_workspace_bytes(self._h, B, H, W)
         if nbytes == 0:
             raise ValueError(f"unsupported input {tuple(x.shape)}")
-        ws = self._workspace(nbytes, x.device)
-        N = self._lib.dod_num_tokens(self._h, H, W)
-        feats = torch.empty(B, N, self.bb.out_dim, dtype=torch.float32, device=x.device)
-        nat.check(self._lib.dod_backbone_forward(self._h, nat.ptr(x), B, H, W, nat.ptr(feats), nat.ptr(ws),
-                                                 ws.numel(), nat.stream_ptr()), self._h)
+        with self._on_device(x):
+            ws = self._workspace(nbytes, x.device)
+            N = self._lib.dod_num_tokens(self._h, H, W)
+            feats = torch.empty(B, N, self.bb.out_dim, dtype=torch.float32, device=x.device)
+            nat.check(self._lib.dod_backbone_forward(self._h, nat.ptr(x), B, H, W, nat.ptr(feats), nat.ptr(ws),
+                                                     ws.numel(), nat.stream_ptr()), self._h)
         return feats
 
     def backbone_prefix(self, pixel_values, named, nblocks):
@@ -160,11 +187,12 @@ class Engine:
         nbytes = self._lib.dod_workspace_bytes(self._h, B, H, W)
         if nbytes == 0:
             raise ValueError(f"unsupported input {tuple(x.shape)}")
-        ws = self._workspace(nbytes, x.device)
-        N = self._lib.dod_num_tokens(self._h, H, W)
-        out = torch.empty(B, N, self.bb.hidden, dtype=torch.float32, device=x.device)
-        nat.check(self._lib.dod_backbone_prefix(self._h, nat.ptr(x), B, H, W, int(nblocks), nat.ptr(out), nat.ptr(ws), ws.numel(),
-                                                nat.stream_ptr()), self._h)
+        with self._on_device(x):
+            ws = self._workspace(nbytes, x.device)
+            N = self._lib.dod_num_tokens(self._h, H, W)
+            out = torch.empty(B, N, self.bb.hidden, dtype=torch.float32, device=x.device)
+            nat.check(self._lib.dod_backbone_prefix(self._h, nat.ptr(x), B, H, W, int(nblocks), nat.ptr(out), nat.ptr(ws), ws.numel(),
+                                                    nat.stream_ptr()), self._h)
         return out
 
     def decoder_forward(self, memory, named):
@@ -176,10 +204,11 @@ class Engine:
         self.sync_weights(named)
         B, N, _ = m.shape
         nbytes = self._lib.dod_decoder_workspace_bytes(self._h, B, N)
-        ws = self._workspace(nbytes, m.device)
-        det = torch.empty(B, self.dc.num_queries, self.dc.num_classes + 4, dtype=torch.float32, device=m.device)
-        nat.check(self._lib.dod_decoder_forward(self._h, nat.ptr(m), B, N, nat.ptr(det), nat.ptr(ws), ws.numel(),
-                                                nat.stream_ptr()), self._h)
+        with self._on_device(m):
+            ws = self._workspace(nbytes, m.device)
+            det = torch.empty(B, self.dc.num_queries, self.dc.num_classes + 4, dtype=torch.float32, device=m.device)
+            nat.check(self._lib.dod_decoder_forward(self._h, nat.ptr(m), B, N, nat.ptr(det), nat.ptr(ws), ws.numel(),
+                                                    nat.stream_ptr()), self._h)
         return det
 
     # ------------------------------------------------------------------ per-kernel timing (bench roofline leg)

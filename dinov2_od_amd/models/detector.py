@@ -8,7 +8,7 @@ from .dinov2_backbone import DINOv2Backbone, _EngineMixin
 from .detr_decoder import DETRDecoder
 
 
-class DINOv2ObjectDetector(nn.Module, _EngineMixin):
+class DINOv2ObjectDetector(_EngineMixin, nn.Module):   # state-dict keys already carry "backbone." / "decoder."
     """Same constructor defaults as the reference (config.py:21-35 via detector.py:9-21).
     Extra keyword arguments: `pretrained`, `precision`, `backbone_config` (micro test models)."""
 
@@ -45,9 +45,6 @@ class DINOv2ObjectDetector(nn.Module, _EngineMixin):
         self._dropout_p = float(dropout)
         self._bb_cfg = self.backbone._bb_cfg
         self._dc_cfg = self.decoder._dc_cfg
-
-    def _engine_named(self):
-        return list(self.state_dict(keep_vars=True).items())    # keys already "backbone." / "decoder."
 
     def enable_hipgraph(self, on=True):
         """eval-mode forwards replay one captured hipGraph per input shape (the returned tensors are the graph's static output

@@ -64,7 +64,7 @@ class MLP(_Box):
         self.mlp = nn.Sequential(*layers)
 
 
-class DETRDecoder(nn.Module, _EngineMixin):
+class DETRDecoder(_EngineMixin, nn.Module):
     """dino_detector/models/detr_decoder.py:7-83; `precision` is the only extra argument."""
 
     def __init__(self, num_queries, hidden_dim, nheads, num_decoder_layers, num_classes,
@@ -94,8 +94,7 @@ class DETRDecoder(nn.Module, _EngineMixin):
         # a stand-alone decoder handle carries a minimal (unused) backbone description
         self._bb_cfg = BackboneConfig(hidden=hidden_dim, layers=1, heads=max(1, hidden_dim // 64), target_dim=0)
 
-    def _engine_named(self):
-        return [("decoder." + k, v) for k, v in self.state_dict(keep_vars=True).items()]
+    _key_prefix = "decoder."
 
     def forward(self, src):
         """src [batch, seq_len, hidden_dim] -> {"pred_logits": [B,Q,C], "pred_boxes": [B,Q,4]}"""

@@ -116,8 +116,33 @@ def _load_pretrained(dino, model_name):
 class _EngineMixin:
     """Lazily creates the native engine and keeps its packed weights in sync with the module."""
 
-    def _engine_named(self):   # list of (reference key, tensor)
-        raise NotImplementedError
+    _key_prefix = ""
+
+    def _engine_named(self):
+        """list of (reference state-dict key, tensor).  Built once (a state_dict() walk of 300+ entries per forward costs
+        more than a small-batch forward does) and dropped by anything that can replace tensors: _apply (.to / .cuda /
+        .float), load_state_dict, or a call of invalidate_weight_cache() after swapping parameters by hand.  In-place
+        updates (optimizer steps, load_state_dict's copy_) keep the list valid and are seen by the engine's
+        (data_ptr, _version) signature."""
+        named = self.__dict__.get("_named_cache")
+        if named is None:
+            named = [(self._key_prefix + k, v) for k, v in self.state_dict(keep_vars=True).items()]
+            self.__dict__["_named_cache"] = named
+        return named
+
+    def invalidate_weight_cache(self):
+        self.__dict__.pop("_named_cache", None)
+        for m in self.children():
+            if isinstance(m, _EngineMixin):
+                m.invalidate_weight_cache()
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_weight_cache()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate_weight_cache()
+        return super().load_state_dict(*a, **k)
 
     def _get_engine(self):
         eng = self.__dict__.get("_engine")
@@ -140,7 +165,7 @@ class _EngineMixin:
         self.__dict__.pop("_engine", None)
 
 
-class DINOv2Backbone(nn.Module, _EngineMixin):
+class DINOv2Backbone(_EngineMixin, nn.Module):
     """dino_detector/models/dinov2_backbone.py:7-67.  Extra keyword arguments (not in the
     reference): `pretrained` (default True, like from_pretrained) and `precision`
     ("bf16" fast path | "fp32" strict parity)."""
@@ -171,8 +196,7 @@ class DINOv2Backbone(nn.Module, _EngineMixin):
         self._dc_cfg = DecoderConfig(num_queries=1, hidden_dim=bb.out_dim, nheads=1 if bb.out_dim <= 128 else bb.out_dim // 64,
                                      num_layers=1, num_classes=1, dim_feedforward=64)
 
-    def _engine_named(self):
-        return [("backbone." + k, v) for k, v in self.state_dict(keep_vars=True).items()]
+    _key_prefix = "backbone."
 
     def forward(self, pixel_values):
         """-> features [batch, seq_len, hidden_dim] fp32, CLS token at index 0 (dinov2_backbone.py:58-67)"""

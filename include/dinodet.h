@@ -32,6 +32,8 @@ extern "C" {
 
 typedef struct dod_handle dod_handle;
 
+enum dod_dtype { DOD_F32 = 0, DOD_BF16 = 1 };
+
 enum dod_status {
   DOD_OK = 0,
   DOD_ERR_INVALID = 1,      /* bad argument / unsupported shape  (Python raises ValueError)   */
@@ -82,11 +84,11 @@ int dod_create(const dod_config* cfg, dod_handle** out);
 void dod_destroy(dod_handle* h);
 const char* dod_last_error(const dod_handle* h);
 
-/* Register one fp32 device tensor under its reference state-dict key
+/* Register one device tensor (dtype DOD_F32, or DOD_BF16 for half-width checkpoints: widened to fp32 while packing) under its reference state-dict key
  * (e.g. "backbone.dino.encoder.layer.3.attention.attention.query.weight",
  *  "...layer.11.mlp.fc1.lora_A.weight", "decoder.decoder.layers.0.cross_attn.value_proj.bias").
  * A leading "module." (DDP, train.py:700-709) is ignored.  Unknown keys are accepted and unused. */
-int dod_set_weight(dod_handle* h, const char* key, const void* dev_ptr, const int64_t* shape, int ndim);
+int dod_set_weight(dod_handle* h, const char* key, const void* dev_ptr, const int64_t* shape, int ndim, int dtype /* dod_dtype */);
 
 /* Build the packed weights (merges W + alpha*B*A, concatenates q/k/v, casts).  Synchronises `stream`
  * once at the end; after it returns the caller's weight tensors are no longer referenced.
@@ -136,7 +138,6 @@ int dod_profile(dod_handle* h, int enable);
 int dod_profile_read(dod_handle* h, int cls, double* ms, double* flops, int* launches);
 
 /* ---- stateless operator entry points (the same kernels the forward uses; for parity tests) ------ */
-enum dod_dtype { DOD_F32 = 0, DOD_BF16 = 1 };
 enum dod_act { DOD_ACT_NONE = 0, DOD_ACT_RELU = 1, DOD_ACT_GELU = 2, DOD_ACT_SIGMOID = 3 };
 
 /* out[M,N] = act(A[M,K] W[N,K]^T + bias) * scale + resid ; A, W of dtype `in_dtype`; bias/scale/resid fp32 or NULL */

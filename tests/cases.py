@@ -60,3 +60,21 @@ def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
+
+
+def vit_full(variant, Q=300):
+    """BASELINE.json configs[3] / configs[4] at full depth: ViT-L/14 (24 blocks) and ViT-g/14 (40 blocks, SwiGLU) with the
+    768-wide projection (dinov2_backbone.py:33-37) and a 300-query decoder (goldens g7_vitl_518 / g8_vitg_518)."""
+    bb = BackboneConfig.from_name(f"facebook/dinov2-{variant}", lora_r=2, lora_alpha=1.0, target_dim=768)
+    dc = DecoderConfig(num_queries=Q, hidden_dim=768, nheads=8, num_layers=3, num_classes=91,
+                       dim_feedforward=1024, n_points=2, use_deformable=True)
+    return bb, dc
+
+
+FULL_DEPTH = {"large": ("g7_vitl_518", (0, 11, 23)), "giant": ("g8_vitg_518", (0, 19, 39))}
+
+
+def probe(a):
+    """the probe slice make_goldens._probe stores for a [B, N, D] activation"""
+    a = np.asarray(a)
+    return a[:, ::max(1, a.shape[1] // 8), :64]

@@ -257,7 +257,13 @@ def g6_matcher():
     _save("g6_matcher", det=det, labels=labels, gt=gt, offs=offs, **out)
 
 
-def _e2e(name, model_name, R, B, kwargs, probes=True):
+def _probe(t):
+    """a small, position-spread probe of a [B, N, D] activation + three checksums of the whole tensor"""
+    a = t.detach().numpy()
+    return a[:, ::max(1, a.shape[1] // 8), :64].copy(), np.array([a.mean(), np.abs(a).mean(), np.sqrt((a.astype(np.float64) ** 2).sum())])
+
+
+def _e2e(name, model_name, R, B, kwargs, probes=True, block_taps=()):
     from dinov2_od_amd.config import variant_of, BACKBONE_VARIANTS
     hid = kwargs.get("hidden_dim", 768)
     bb = BackboneConfig.from_name(model_name, lora_r=kwargs.get("lora_r", 2), lora_alpha=1.0, target_dim=hid)
@@ -271,13 +277,24 @@ def _e2e(name, model_name, R, B, kwargs, probes=True):
     sd = synth.detector_state_dict(bb, dc, seed=1)
     _load(m, sd)
     x = synth.make_pixels(B, R, R, seed=0)
+    del sd
+    taps, hooks = {}, []
+    if block_taps:   # full-depth fixtures: probes of the embeddings and of chosen block outputs (per-stage parity on the GPU)
+        hooks.append(m.backbone.dino.embeddings.register_forward_hook(lambda mod, i, o: taps.__setitem__("embeddings", _probe(o))))
+        for li in block_taps:
+            hooks.append(m.backbone.dino.encoder.layer[li].register_forward_hook(
+                lambda mod, i, o, li=li: taps.__setitem__(f"block{li}", _probe(o[0] if isinstance(o, tuple) else o))))
     with torch.no_grad():
         feats = m.backbone(torch.from_numpy(x))
         o = m.decoder(feats)
+    for h in hooks:
+        h.remove()
     f = feats.numpy()
     arrs = dict(pred_logits=o["pred_logits"].numpy(), pred_boxes=o["pred_boxes"].numpy(),
                 feat_probe=f[:, ::max(1, f.shape[1] // 8), :64].copy(),
                 feat_stats=np.array([f.mean(), np.abs(f).mean(), np.sqrt((f.astype(np.float64) ** 2).sum())]))
+    for k, (pr, st) in taps.items():
+        arrs[k + "_probe"], arrs[k + "_stats"] = pr, st
     _save(name, **arrs)
 
 
@@ -296,8 +313,18 @@ def g3_vitb():
     _e2e("g3_vitb_224_dense", "facebook/dinov2-base", 224, 1, dict(num_queries=100, use_deformable=False))
 
 
+def g7_vitl():
+    """BASELINE.json configs[3] at its workload: ViT-L/14 518x518, 300 queries, full depth (24 blocks), one image."""
+    _e2e("g7_vitl_518", "facebook/dinov2-large", 518, 1, dict(num_queries=300), block_taps=(0, 11, 23))
+
+
+def g8_vitg():
+    """BASELINE.json configs[4] at its workload: ViT-g/14 518x518 (SwiGLU, 40 blocks), 300 queries, one image."""
+    _e2e("g8_vitg_518", "facebook/dinov2-giant", 518, 1, dict(num_queries=300), block_taps=(0, 19, 39))
+
+
 CASES = dict(g0=lambda: g0_micro_backbone(False), g4=lambda: g0_micro_backbone(True),
-             g1=g1_decoder_only, g2=g2_cfg1, g3=g3_vitb, g5=g5_postprocess, g6=g6_matcher)
+             g1=g1_decoder_only, g2=g2_cfg1, g3=g3_vitb, g5=g5_postprocess, g6=g6_matcher, g7=g7_vitl, g8=g8_vitg)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -58,3 +58,42 @@ def test_shard_bounds_cover_batch():
             assert spans[0][0] == 0 and spans[-1][1] == gb
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_bench_self_launches_ranks_and_gathers(tmp_path):
+    """`python bench.py --gpus 2` with no torchrun environment: the parent spawns two fresh rank processes (dinov2_od_amd/launch.py,
+    the reference's mp.spawn at train.py:1501-1506), they rendezvous on 127.0.0.1 over gloo, run the sharded step loop with the
+    gather and rank 0 prints the one JSON line.  --rehearse-cpu swaps the model for a stub: control flow only."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse-cpu"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["n_ranks_seen"] == 2 and j["config"]["global_batch"] == 128
+    assert j["config"]["gather_checked"] is True
+    assert j["data"] == "rehearsal-cpu" and j["metric"].startswith("REHEARSAL")
+    assert j["global64_sharded"]["per_gpu_batch"] == 32 and j["global64_sharded"]["scaling"] == "strong"
+    assert j["steps"] == 3 and j["value"] > 0
+
+
+def test_launcher_propagates_a_failing_rank(tmp_path):
+    from dinov2_od_amd.launch import spawn_ranks
+    import io
+    script = tmp_path / "child.py"
+    script.write_text("import os, sys, time\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "print('hello from', r, flush=True)\n"
+                      "if r == 1: sys.exit(7)\n"
+                      "time.sleep(30)\n")          # rank 0 would wait in a collective: the launcher must end it
+    out, err = io.StringIO(), io.StringIO()
+    t0 = __import__("time").time()
+    rc = spawn_ranks(str(script), [], 2, timeout=60, stdout=out, stderr=err)
+    assert rc == 7 and __import__("time").time() - t0 < 25
+    assert "hello from 0" in out.getvalue() and "hello from 1" in err.getvalue()

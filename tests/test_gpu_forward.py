@@ -39,6 +39,8 @@ def _taps(m, B, N, bb, dc):
     return t
 
 
+K_BF16 = 1.5    # HIP-vs-fp32 distance allowed, in units of the bf16-faithful oracle's own distance to fp32
+
 # parity-gated modes: "fp32" (exact-fp32 MFMA / VALU) and "bf16x3" (split products on the bf16 MFMA kernels, ~1e-5)
 GATED = ["fp32", "bf16x3"]
 
@@ -173,18 +175,27 @@ def test_bf16_vitb_vs_bf16_faithful_oracle_and_fp32_reference(G, R, B):
     print(f"bf16 features R={R}: rel-L2 vs bf16-faithful oracle {e_emu:.2e}, vs fp32 oracle {e_f32:.2e}")
     assert e_emu < 8e-3 and e_f32 < 8e-3
     el, eb = rel_l2(out["pred_logits"].cpu().numpy(), f32["pred_logits"].numpy()), rel_l2(out["pred_boxes"].cpu().numpy(), f32["pred_boxes"].numpy())
-    print(f"bf16 outputs R={R}: rel-L2 logits {el:.2e} boxes {eb:.2e} vs fp32 oracle")
-    assert el < 8e-2 and eb < 3e-2
+    # the yardstick is what bf16 operand rounding itself costs: the bf16-faithful oracle's own distance to the fp32 oracle.
+    # The HIP path must not be further away than that (x K_BF16: two evaluations with the same rounding points are two
+    # draws of the same error, not the same draw), so a kernel regression that costs accuracy shows up here.
+    ol, ob = rel_l2(emu["pred_logits"].numpy(), f32["pred_logits"].numpy()), rel_l2(emu["pred_boxes"].numpy(), f32["pred_boxes"].numpy())
+    print(f"bf16 outputs R={R}: rel-L2 vs fp32 oracle: logits {el:.2e} (bf16-faithful oracle {ol:.2e}), boxes {eb:.2e} ({ob:.2e})")
+    assert e_f32 < K_BF16 * rel_l2(emu["features"].numpy(), f32["features"].numpy())
+    assert el < K_BF16 * ol and eb < K_BF16 * ob
 
 
 def test_bf16_cfg1_end_to_end(G):
     g = cases.golden("g2_cfg1_q100")
     bb, dc = cases.cfg1(100)
     m = G.make_detector(bb, dc, "bf16", "facebook/dinov2-small")
-    out = m(G.to_gpu(synth.make_pixels(2, 224, 224, seed=0)))
+    x = synth.make_pixels(2, 224, 224, seed=0)
+    out = m(G.to_gpu(x))
     G.sync()
-    assert rel_err(out["pred_logits"].cpu().numpy(), g["pred_logits"]) < 1e-2
-    assert rel_err(out["pred_boxes"].cpu().numpy(), g["pred_boxes"]) < 1e-2
+    emu = orc.detector_forward(synth.detector_state_dict(bb, dc, seed=1), bb, dc, x, emulate_bf16=True)
+    for k in ("pred_logits", "pred_boxes"):
+        got, floor = rel_l2(out[k].cpu().numpy(), g[k]), rel_l2(emu[k].numpy(), g[k])
+        print(f"bf16 cfg1 {k}: rel-L2 vs the reference {got:.2e} (bf16-faithful oracle {floor:.2e})")
+        assert got < K_BF16 * floor, (k, got, floor)
 
 
 def test_weights_resync_after_load_state_dict(G):
@@ -288,6 +299,42 @@ def test_hipgraph_replay_matches_eager_and_tracks_weight_updates(G):
     assert torch.equal(m.forward_packed(xa), g2) and not torch.equal(g2, ea)
 
 
+def test_hipgraph_small_shape_survives_a_later_larger_one(G):
+    """a captured graph bakes in the address of its workspace: a later, larger shape (or an eager call that needs more scratch)
+    must not pull it from under the earlier graph.  Capture small, then large, run eager calls of other shapes, replay small."""
+    bb, dc = cases.cfg1(25)
+    m = G.make_detector(bb, dc, "bf16", "facebook/dinov2-small")
+    xs = G.to_gpu(synth.make_pixels(1, 70, 112, seed=3))
+    xl = G.to_gpu(synth.make_pixels(3, 224, 224, seed=0))
+    m.enable_hipgraph()
+    a_small = m.forward_packed(xs).clone()               # captures the small shape FIRST (workspace sized for it)
+    a_large = m.forward_packed(xl).clone()               # larger capture
+    m.enable_hipgraph(False)
+    e_small, e_large = m.forward_packed(xs).clone(), m.forward_packed(xl).clone()     # eager: grows the shared eager workspace
+    junk = [torch.full((1 << 22,), float("nan"), device=G.dev()) for _ in range(8)]   # reuse whatever the allocator freed
+    m.enable_hipgraph()
+    for _ in range(2):
+        assert torch.equal(m.forward_packed(xs), e_small) and torch.equal(a_small, e_small)
+        assert torch.equal(m.forward_packed(xl), e_large) and torch.equal(a_large, e_large)
+    del junk
+
+
+def test_alternating_input_sizes_reuse_position_tables(G):
+    """one interpolated position table per distinct (H, W), cached in the handle: alternating sizes stay bit-identical and
+    allocate nothing after the first visit"""
+    bb, dc = cases.cfg1(25)
+    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-small")
+    xa = G.to_gpu(synth.make_pixels(1, 70, 112, seed=3))
+    xb = G.to_gpu(synth.make_pixels(1, 112, 70, seed=3))
+    ra, rb = m.forward_packed(xa).clone(), m.forward_packed(xb).clone()
+    G.sync()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        assert torch.equal(m.forward_packed(xa), ra) and torch.equal(m.forward_packed(xb), rb)
+    G.sync()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)      # no per-forward hipMalloc
+
+
 @pytest.mark.parametrize("precision", GATED + ["bf16"])
 def test_degenerate_images(G, precision):
     """constant images (all zeros / all ones: identical patches, attention rows uniform) and a mixed batch: finite everywhere,
@@ -378,11 +425,14 @@ def test_large_and_giant_shaped_models_two_blocks(G, variant, precision):
             assert got < max(TOL, (3.0 if precision == "fp32" else 5.0) * floor), (k, got, floor)
     else:
         want = orc.detector_forward(sd, bb, dc, x, emulate_bf16=True)
+        exact = orc.detector_forward(sd, bb, dc, x)
         assert rel_l2(mem.cpu().numpy(), want["features"].numpy()) < 8e-3
-        # two bf16 evaluations decorrelate to the bf16 noise level on the features (< 8e-3) and this decoder config
-        # amplifies that ~10x per layer (see the fp32 branch): bounded, loosely
-        assert rel_l2(out["pred_logits"].cpu().numpy(), want["pred_logits"].numpy()) < 0.25
-        assert rel_l2(out["pred_boxes"].cpu().numpy(), want["pred_boxes"].numpy()) < 0.1
+        # two bf16 evaluations decorrelate to the bf16 noise level on the features and this decoder config amplifies that
+        # ~10x per layer (see the fp32 branch): the HIP path may be as far from fp32 as the bf16-faithful oracle is (x K_BF16)
+        for k, hip in (("features", mem), ("pred_logits", out["pred_logits"]), ("pred_boxes", out["pred_boxes"])):
+            got, floor = rel_l2(hip.cpu().numpy(), exact[k].numpy()), rel_l2(want[k].numpy(), exact[k].numpy())
+            print(f"bf16 {variant} {k}: rel-L2 vs fp32 oracle {got:.2e} (bf16-faithful oracle {floor:.2e})")
+            assert got < K_BF16 * floor, (k, got, floor)
 
 
 def test_non_square_and_odd_sizes_strict(G):
@@ -402,3 +452,114 @@ def test_non_square_and_odd_sizes_strict(G):
         want = orc.backbone_forward(sdp, bb, x)
         assert f.shape == want.shape
         assert rel_err(f.cpu().numpy(), want.numpy()) < 1e-5, (H, W)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] / configs[4] at their workload: full depth, 518x518, 300 queries (goldens G7 / G8 from the reference itself)
+_FULL_SD = {}
+
+
+def _full_detector(G, variant, precision):
+    """the synthetic state dict of a 0.3 / 1.1 G-parameter model takes a while to hash: generated once per variant"""
+    from dinov2_od_amd.models import DINOv2ObjectDetector
+    bb, dc = cases.vit_full(variant)
+    if variant not in _FULL_SD:
+        _FULL_SD.clear()                                 # one variant resident at a time (ViT-g: 4.5 GB of fp32)
+        _FULL_SD[variant] = synth.detector_state_dict(bb, dc, seed=1)
+    m = DINOv2ObjectDetector(num_classes=dc.num_classes, dino_model_name=f"facebook/dinov2-{variant}", lora_r=bb.lora_r,
+                             lora_alpha=bb.lora_alpha, hidden_dim=dc.hidden_dim, num_queries=dc.num_queries, nheads=dc.nheads,
+                             num_decoder_layers=dc.num_layers, dim_feedforward=dc.dim_feedforward, n_points=dc.n_points,
+                             use_deformable=True, pretrained=False, precision=precision, backbone_config=bb)
+    G.load_np_state(m, _FULL_SD[variant])
+    return m.to(G.dev()).eval(), bb, dc
+
+
+def _full_run(G, variant, precision):
+    name, blocks = cases.FULL_DEPTH[variant]
+    m, bb, dc = _full_detector(G, variant, precision)
+    N = num_tokens(518, 518)
+    eng = m._get_engine()
+    taps = {"embeddings": eng.set_tap(0, (1, N, bb.hidden), "cuda:0"), "feat": eng.set_tap(1000, (1, N, 768), "cuda:0")}
+    for b in blocks:
+        taps[f"block{b}"] = eng.set_tap(1 + b, (1, N, bb.hidden), "cuda:0")
+    out = m(G.to_gpu(synth.make_pixels(1, 518, 518, seed=0)))
+    G.sync()
+    res = {k: cases.probe(v.cpu().numpy()) for k, v in taps.items()}
+    res["pred_logits"], res["pred_boxes"] = out["pred_logits"].cpu().numpy(), out["pred_boxes"].cpu().numpy()
+    eng.clear_taps()
+    del m
+    torch.cuda.empty_cache()
+    return res, blocks, cases.golden(name)
+
+
+@pytest.mark.parametrize("variant", ["large", "giant"])
+@pytest.mark.parametrize("precision", GATED)
+def test_full_depth_configs_gated_vs_reference(G, variant, precision):
+    """configs[3] ViT-L/14 and configs[4] ViT-g/14 (SwiGLU, 40 blocks) at 518x518 with 300 queries, ALL blocks, one image:
+    both parity-gated modes against the REFERENCE's own forward (G7 / G8: modeling_dinov2.py:300-314 at depth, the 1024 /
+    1536 -> 768 projection dinov2_backbone.py:33-37,64-65) -- per-stage probes and the 1e-3 gate on logits and boxes."""
+    r, blocks, g = _full_run(G, variant, precision)
+    stage = 2e-5 if precision == "fp32" else 2e-4          # bf16x3 drops the lo*lo products: 2^-18 per product, x depth
+    assert rel_err(r["embeddings"], g["embeddings_probe"]) < 1e-5
+    for b in blocks:
+        e = rel_err(r[f"block{b}"], g[f"block{b}_probe"])
+        print(f"{variant} {precision} block{b}: {e:.2e}")
+        assert e < stage, (b, e)
+    e = rel_err(r["feat"], g["feat_probe"])
+    print(f"{variant} {precision} features: {e:.2e}")
+    assert e < stage
+    for k in ("pred_logits", "pred_boxes"):
+        e = rel_err(r[k], g[k])
+        print(f"{variant} {precision} {k}: {e:.2e} (gate {TOL:g})")
+        assert e < TOL, (k, e)
+
+
+@pytest.mark.parametrize("variant,precision", [("large", "bf16"), ("giant", "bf16"), ("giant", "fp8")])
+def test_full_depth_configs_throughput_modes(G, variant, precision):
+    """The same two configurations in the opt-in throughput modes (configs[3] is quoted in bf16, configs[4] in fp8), full depth.
+    Held (a) stage by stage to the oracle evaluated with the SAME operand rounding (tests/golden/emu_*.npz, generated by
+    tests/golden/make_emu_fixtures.py from the CPU oracle: tight on the embeddings and block 0, where two evaluations have not
+    decorrelated yet) and (b) on features / logits / boxes to the REFERENCE (G7 / G8): no further from it than that faithful
+    oracle is, x K -- so an accuracy regression of a kernel is visible at the configuration's real depth."""
+    r, blocks, g = _full_run(G, variant, precision)
+    emu = cases.golden("emu_" + cases.FULL_DEPTH[variant][0])
+    p = precision + "_"
+    assert rel_err(r["embeddings"], emu[p + "embeddings_probe"]) < 1e-5
+    e0 = rel_err(r[f"block{blocks[0]}"], emu[p + f"block{blocks[0]}_probe"])
+    print(f"{variant} {precision} block0 vs faithful oracle: {e0:.2e}")
+    assert e0 < (4e-3 if precision == "bf16" else 4e-2)          # one bf16 ulp = 3.9e-3; one e4m3 step = 6e-2
+    K = 1.5
+    for b in blocks[1:]:
+        got, floor = rel_l2(r[f"block{b}"], g[f"block{b}_probe"]), rel_l2(emu[p + f"block{b}_probe"], g[f"block{b}_probe"])
+        print(f"{variant} {precision} block{b}: rel-L2 vs the reference {got:.2e} (faithful oracle {floor:.2e})")
+        assert got < K * floor, (b, got, floor)
+    for k, gk, ek in (("feat", "feat_probe", p + "feat_probe"), ("pred_logits", "pred_logits", p + "pred_logits"), ("pred_boxes", "pred_boxes", p + "pred_boxes")):
+        got, floor = rel_l2(r[k], g[gk]), rel_l2(emu[ek], g[gk])
+        print(f"{variant} {precision} {k}: rel-L2 vs the reference {got:.2e} (faithful oracle {floor:.2e})")
+        assert np.isfinite(r[k]).all() and got < K * floor, (k, got, floor)
+
+
+@pytest.mark.parametrize("precision", GATED)
+def test_reference_point_conditioning_sweep(G, precision):
+    """The synthetic reference_points_proj weight uses sigma = 0.01 so that the fp32 noise floor on the logits leaves a margin
+    under the 1e-3 gate (a reference-point error d moves a sample by d (w - 1) = 136..256 tokens).  This sweep records how the
+    error grows with sigma (0.01, 0.03): the HIP path against the EXACT (fp64) result next to the fp32 CPU evaluation against
+    the same -- the HIP path must track the fp32 evaluation's own floor (x3), whatever the conditioning."""
+    bb, dc = cases.vitb(100, True)
+    x = synth.make_pixels(1, 224, 224, seed=0)
+    for sigma in (0.01, 0.03):
+        sd = dict(synth.detector_state_dict(bb, dc, seed=1))
+        w = sd["decoder.decoder.layers.0.reference_points_proj.weight"] * np.float32(sigma / 0.01)
+        for j in range(dc.num_layers):                   # tied layers: one array under every j
+            sd[f"decoder.decoder.layers.{j}.reference_points_proj.weight"] = w
+        m = G.make_detector(bb, dc, precision, "facebook/dinov2-base")
+        G.load_np_state(m, sd)
+        out = m(G.to_gpu(x))
+        G.sync()
+        exact = orc.detector_forward(sd, bb, dc, x, dtype=torch.float64)
+        f32 = orc.detector_forward(sd, bb, dc, x)
+        for k in ("pred_logits", "pred_boxes"):
+            got = rel_err(out[k].cpu().numpy(), exact[k].numpy())
+            floor = rel_err(f32[k].numpy(), exact[k].numpy())
+            print(f"sigma {sigma} {precision} {k}: HIP vs fp64 {got:.2e}, fp32 CPU vs fp64 {floor:.2e}")
+            assert got < max(TOL if sigma == 0.01 else 0.0, (3.0 if precision == "fp32" else 5.0) * floor), (sigma, k, got, floor)
