@@ -1,0 +1,203 @@
+// bf16 MFMA GEMM, 256x256x64 tile, 8 waves in two groups that run half a phase apart ("ping-pong"): while one group's
+// waves issue MFMAs the other group's read their next fragments from LDS and issue the staging DMA, so each SIMD's
+// matrix pipe always has one of its two waves feeding it.  Same nn.Linear sites as gemm_bf16.hip
+// (modeling_dinov2.py:199-201, 246-252, 281-297); C[M,N] = A[M,K] W[N,K]^T, fp32 accumulate, shared epilogue (gemm_epi.h).
+//
+// Structure (guide: cdna_hip_programming.md section 5, "256^2 8-phase template", re-derived for this LDS image):
+//   * wave (g, q), g = wid >> 2 the group, q = wid & 3: output rows g*128..+127, columns q*64..+63 -> 8 x 4 accumulator
+//     blocks of 16x16 (128 registers), product computed transposed (lane owns an output row, registers run along n).
+//   * a K-tile (64 k) is 4 PLANES of 16 KiB in LDS: A k0..31 | A k32..63 | W k0..31 | W k32..63, each [256 rows][64 B],
+//     16-B chunk swizzled by row bit 3 (the conflict-free image of gemm_x3.hip); two K-tile buffers = 128 KiB.
+//   * a K-tile is consumed in 4 phases (k half kh = p >> 1, row half mh = p & 1), 16 MFMAs each.  Per phase a wave does
+//       LOAD:    ds_read the phase's fragments (W fragments once per k half), issue ONE plane of prefetch (2 LDS-DMA),
+//                wait for its LDS reads (and, twice per K-tile, the counted vmcnt), barrier
+//       COMPUTE: 16 MFMAs, barrier
+//     Group 1 starts one barrier late, so its LOAD runs beside group 0's COMPUTE and vice versa.
+//   * prefetch: planes are refilled as soon as every wave has read them -- the k-half-0 planes of tile t+2 during phases
+//     2, 3 of tile t, the k-half-1 planes during phases 0, 1 of tile t+1 -- so each plane has 8-10 half-phases (~1 us) of
+//     flight; s_waitcnt vmcnt(8) at the end of LOAD 1 and LOAD 3 (never 0 inside the loop), raw s_barrier.
+//   * WAR: the LDS reads of a phase are retired (lgkmcnt(0)) BEFORE the barrier that ends the LOAD segment; a plane is
+//     re-staged only after the barrier following group 1's last read of it.  RAW: a plane is read one barrier (at least)
+//     after the barrier that follows every wave's vmcnt wait for it.
+#include "dod_common.h"
+#include "gemm_epi.h"
+#include <cstdlib>
+
+#define PPM 256
+#define PPN 256
+#define PPK 64
+#define PP_PLANE (256 * 64)               // one 256-row x 32-k bf16 plane: 16 KiB
+#define PP_TILE (4 * PP_PLANE)            // A k0 | A k1 | W k0 | W k1 = 64 KiB
+
+__device__ __forceinline__ int pp_swz(int row, int chunk) { return chunk ^ (((row >> 3) & 1) << 1); }   // 16x16x32 lane map, 64-B rows
+
+__global__ __launch_bounds__(512) void gemm_pp_256x256_kernel(const bf16_t* __restrict__ A, int lda,
+                                                              const bf16_t* __restrict__ W, int ldw, int M, int N,
+                                                              int K, GemmEpi e, int GM) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const int grp_ = wu >> 2, wq = wu & 3;
+  const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  {
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = bid - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
+  const int m0 = tm * PPM, n0 = tn * PPN;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // staging: per plane a wave issues two 16-row pieces (rows wid*32 + {0..15}, {16..31}); lane -> (row = lane >> 2,
+  // LDS chunk slot lane & 3), fetching global chunk slot ^ swizzle(row)
+  const bf16_t *gA0, *gA1, *gW0, *gW1;
+  {
+    const int rl = wid * 32 + (lane >> 2);
+    const int c = pp_swz(rl, lane & 3);          // rows rl and rl + 16 share row bit 3
+    int ra0 = m0 + rl, ra1 = m0 + rl + 16; ra0 = ra0 < M ? ra0 : M - 1; ra1 = ra1 < M ? ra1 : M - 1;
+    int rw0 = n0 + rl, rw1 = n0 + rl + 16; rw0 = rw0 < N ? rw0 : N - 1; rw1 = rw1 < N ? rw1 : N - 1;
+    gA0 = A + (size_t)ra0 * lda + c * 8; gA1 = A + (size_t)ra1 * lda + c * 8;
+    gW0 = W + (size_t)rw0 * ldw + c * 8; gW1 = W + (size_t)rw1 * ldw + c * 8;
+  }
+  char* const sdst = smem + wu * 2048;
+  // plane pl (0: A k0, 1: A k1, 2: W k0, 3: W k1) of K-tile t -> buffer t & 1
+#define PP_STAGE(t, pl)                                                                                        \
+  {                                                                                                            \
+    char* d_ = sdst + ((t) & 1) * PP_TILE + (pl) * PP_PLANE;                                                   \
+    const int ko_ = (t) * PPK + ((pl) & 1) * 32;                                                               \
+    if ((pl) < 2) {                                                                                            \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + ko_), (lptr_t)(d_), 16, 0, 0);                           \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + ko_), (lptr_t)(d_ + 1024), 16, 0, 0);                    \
+    } else {                                                                                                   \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + ko_), (lptr_t)(d_), 16, 0, 0);                           \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gW1 + ko_), (lptr_t)(d_ + 1024), 16, 0, 0);                    \
+    }                                                                                                          \
+  }
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = K / PPK;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // fragment byte offsets inside a K-tile buffer (k half 0; + PP_PLANE for k half 1)
+  int offA[8], offW[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int row = grp_ * 128 + i * 16 + l15; offA[i] = row * 64 + pp_swz(row, l4) * 16; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int row = wq * 64 + j * 16 + l15; offW[j] = 2 * PP_PLANE + row * 64 + pp_swz(row, l4) * 16; }
+
+  // prologue: tile 0 whole, k half 0 of tile 1 (the rest follows the steady-state schedule from phase 0 on)
+  PP_STAGE(0, 0) PP_STAGE(0, 2) PP_STAGE(0, 1) PP_STAGE(0, 3)
+  if (nk > 1) { PP_STAGE(1, 0) PP_STAGE(1, 2) }
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp_ == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one segment behind group 0
+  asm volatile("" ::: "memory");
+
+  bf16x8 wf[4], af[4];
+  // one phase.  PF: 0 = nothing to prefetch, else the (tile, plane) staged in this LOAD segment.  VW: vmcnt immediate to wait
+  // for at the end of the LOAD segment (-1: none).
+#define PP_PHASE(st, p, PF_ON, PF_T, PF_PL, VW)                                                                \
+  {                                                                                                            \
+    constexpr int kh_ = (p) >> 1, mh_ = (p) & 1;                                                               \
+    if (mh_ == 0) {                                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>((st) + offW[j] + kh_ * PP_PLANE); \
+    }                                                                                                          \
+    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) af[ii] = *reinterpret_cast<const bf16x8*>((st) + offA[4 * mh_ + ii] + kh_ * PP_PLANE); \
+    if (PF_ON) PP_STAGE(PF_T, PF_PL)                                                                           \
+    if ((VW) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                            \
+    else if ((VW) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                       \
+    else if ((VW) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                           \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+        acc[4 * mh_ + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[ii], acc[4 * mh_ + ii][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  }
+
+  int u = 0;
+  // steady state: tiles u with u + 2 < nk
+  for (; u + 2 < nk; ++u) {
+    const char* st = smem + (u & 1) * PP_TILE;
+    PP_PHASE(st, 0, true, u + 1, 1, -1)
+    PP_PHASE(st, 1, true, u + 1, 3, 8)          // k-half-1 planes of tile u landed (4 planes issued since)
+    PP_PHASE(st, 2, true, u + 2, 0, -1)
+    PP_PHASE(st, 3, true, u + 2, 2, 8)          // k-half-0 planes of tile u + 1 landed
+  }
+  if (u + 1 < nk) {                             // second-to-last tile: nothing left to stage beyond tile u + 1
+    const char* st = smem + (u & 1) * PP_TILE;
+    PP_PHASE(st, 0, true, u + 1, 1, -1)
+    PP_PHASE(st, 1, true, u + 1, 3, 8)
+    PP_PHASE(st, 2, false, 0, 0, -1)
+    PP_PHASE(st, 3, false, 0, 0, 4)             // k-half-0 of tile u + 1; younger: its two k-half-1 planes
+    ++u;
+  }
+  {                                             // last tile
+    const char* st = smem + (u & 1) * PP_TILE;
+    PP_PHASE(st, 0, false, 0, 0, -1)
+    PP_PHASE(st, 1, false, 0, 0, 0)             // k-half-1 planes of the last tile
+    PP_PHASE(st, 2, false, 0, 0, -1)
+    PP_PHASE(st, 3, false, 0, 0, -1)
+  }
+  if (grp_ == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last barrier: every LDS read has retired
+  asm volatile("" ::: "memory");
+
+  // epilogue: two passes of 128 tile rows (64 of each group) through a 128 x 256 fp32 LDS tile (pitch +16 B)
+  constexpr int PITCH = PPN * 4 + 16;
+  const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row_l = grp_ * 64 + ii * 16 + l15;
+        const int col = wq * 64 + j * 16 + 4 * l4;
+        const f32x4 a = acc[pass * 4 + ii][j];
+        *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+    __syncthreads();
+    drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid,
+                              [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+  }
+}
+
+static constexpr int LDSPP = (128 * (PPN * 4 + 16)) > 2 * PP_TILE ? (128 * (PPN * 4 + 16)) : 2 * PP_TILE;
+
+// K % 64 == 0, K >= 64
+int launch_gemm_bf16_pp(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % PPK != 0) return 2;
+  if (N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || e.ldc % 4 != 0) return 2;
+  if (e.resid && e.ldr % 4 != 0) return 2;
+  if (!e.out_f32 && !e.out_bf16) return 2;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
+    attr_set[dev] = true;
+  }
+  static const char* gme = getenv("DINODET_GEMM_GM");
+  const int gm = gme ? atoi(gme) : 4;
+  const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
+  hipLaunchKernelGGL(gemm_pp_256x256_kernel, dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
