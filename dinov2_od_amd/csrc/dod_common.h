@@ -140,8 +140,11 @@ int launch_split3(const float* in, int ld_in, bf16_t* out, int rows, int K, int 
 int launch_split2(const float* in, int ld_in, bf16_t* out, int rows, int K, hipStream_t s);   // [hi | lo], pitch 2K
 // split-product GEMM on pair-layout operands A2 [M, 2K], W2 [N, 2K] (gemm_x3.hip)
 int launch_gemm_bf16_k64(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
+int gemm_tile_mode();   // tile-order mode word of the 256-row kernels (gemm_x3.hip; gemm_epi.h tile_map)
 // 256x256x64 ping-pong kernel (gemm_pp.hip): K % 64 == 0
 int launch_gemm_bf16_pp(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
+int launch_gemm_bf16_ppm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
+int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 int launch_gemm_x3(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 // tgt[b][q][:] = query_embed[q][:]
 int launch_bcast_rows(const float* src, float* dst, int B, int rows, int D, hipStream_t s);

@@ -530,20 +530,8 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
   unsigned long long* stamps = g_gemm_stamps;
   unsigned long long t_start = 0, t_loop = 0;
   if (stamps) t_start = __builtin_amdgcn_s_memrealtime();
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   int tm, tn;
-  {
-    const int per_group = GM * tiles_n;
-    const int grp = bid / per_group, first_m = grp * GM;
-    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-    const int in_g = bid - grp * per_group;
-    tm = first_m + in_g % gsz;
-    tn = in_g / gsz;
-  }
+  tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
   const int m0 = tm * B5M, n0 = tn * B5N;
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -782,6 +770,7 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   // one workgroup per CU nothing hides the GELU epilogue, so activations with a transcendental stay on the 2-workgroup kernel.
   // (also at small grids: at M = 10960 -- batch 8 -- QKV 730 vs 639, out-proj 396 vs 375, fc2 634 vs 526 TFLOP/s)
   if (force && force[0] == 'p' && K % 64 == 0) return launch_gemm_bf16_pp(A, lda, W, ldw, M, N, K, e, s);
+  if (force && force[0] == 'q' && K % 64 == 0) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
   if (force ? force[0] == 'x' : (M >= 4096 && N >= 512 && e.act != ACT_GELU && e.act != ACT_SIGMOID && e.rows_per_img == 0))
     return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
   // shape heuristic (measured on MI355X, tools/bench_gemm_k.py / bench_ops.py at M = 87680, random data):
@@ -805,7 +794,7 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   } else if (m16) {
     // grouped-order depth (m-tiles per group inside an XCD's run), measured: 8 for N = 3072, 4 for 2304, 2 for 768
     static const char* gme = getenv("DINODET_GEMM_GM");
-    const int gm = gme ? atoi(gme) : (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2));
+    const int gm = (gme ? (atoi(gme) & 0xff) : (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2))) | (gemm_tile_mode() & 0x300);
     const int tiles = ((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
     hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e, gm);
   } else if (force && force[0] == '7') {

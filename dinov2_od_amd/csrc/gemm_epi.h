@@ -5,6 +5,48 @@
 // 64-byte LDS rows read by 32-row MFMA lane groups: 16-B chunk ^= (row >> 2) & 3 (conflict-free ds_read_b128)
 __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
 
+// ---- workgroup -> output tile map (256x256 kernels) -----------------------------------------------------------------------
+// mode bits: low 8 = GM (m-tiles per group), 0x100 = reverse the m order, 0x200 = time-ordered ("chunked") map.
+// Classic map: each XCD (blocks b, b+8, ... share an L2) gets ONE contiguous run of the tile list, walked in groups of GM m-tiles
+// x all n-tiles: the 8 XCDs sweep 8 different eighths of M at the same time.
+// Chunked map: the tile list is cut into chunks of 8 groups; group k of a chunk runs on XCD k, chunks run one after the other, so
+// the whole chip moves through M together -- in the order the producer kernel wrote the A rows (or, with the reverse bit, most
+// recently written rows first: those are the ones still in the 256-MiB Infinity Cache).  Both maps are bijections for any grid.
+__device__ __forceinline__ void tile_map(int b, int tiles_m, int tiles_n, int mode, int* tm_out, int* tn_out) {
+  const int GM = mode & 0xff;
+  const int nwg = tiles_m * tiles_n;
+  int tm, tn;
+  if (mode & 0x200) {
+    const int per_group = GM * tiles_n;
+    const int nfull = tiles_m / (8 * GM);                  // full chunks
+    const int body = nfull * 8 * per_group;
+    if (b < body) {
+      const int xcd = b & 7, idx = b >> 3;
+      const int chunk = idx / per_group, in_g = idx - chunk * per_group;
+      tm = (chunk * 8 + xcd) * GM + in_g % GM;
+      tn = in_g / GM;
+    } else {                                               // ragged tail: fewer than 8 GM m-tiles
+      const int t = b - body, R = tiles_m - nfull * 8 * GM;
+      tm = nfull * 8 * GM + t % R;
+      tn = t / R;
+    }
+  } else {
+    int bid = b;
+    {
+      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = bid - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
+  if (mode & 0x100) tm = tiles_m - 1 - tm;
+  *tm_out = tm; *tn_out = tn;
+}
+
 // ---- epilogue, staged through LDS so that HBM sees whole rows ---------------------------------------
 // Phase 1 (stage_acc): a lane owns output row m and its register quads 4 consecutive n: it applies
 // bias / activation / LayerScale (float4 per-n parameter reads) and writes float4s into an fp32 LDS

@@ -39,21 +39,8 @@ __global__ __launch_bounds__(512) void gemm_pp_256x256_kernel(const bf16_t* __re
   const int wu = __builtin_amdgcn_readfirstlane(wid);
   const int grp_ = wu >> 2, wq = wu & 3;
   const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   int tm, tn;
-  {
-    const int per_group = GM * tiles_n;
-    const int grp = bid / per_group, first_m = grp * GM;
-    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-    const int in_g = bid - grp * per_group;
-    tm = first_m + in_g % gsz;
-    tn = in_g / gsz;
-  }
+  tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
   const int m0 = tm * PPM, n0 = tn * PPN;
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -180,6 +167,166 @@ __global__ __launch_bounds__(512) void gemm_pp_256x256_kernel(const bf16_t* __re
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same ping-pong structure with phases along m (quarter q = rows 32q..32q+31 of the wave's 128): every phase needs all
+// four planes, the W fragments (all 4 n-blocks of both W planes: 32 registers) are read once per K-tile in phase 0.
+//   X3 = false: plain bf16, planes = A k0..31 | A k32..63 | W k0..31 | W k32..63, 2 MFMAs per 16x16 block and K-tile (BK = 64)
+//   X3 = true : the split product of gemm_x3.hip on PAIR-layout operands (A2 [M, 2K] = [Ah | Al], W2 [N, 2K] = [Wh | Wl]):
+//               planes = Ah | Al | Wh | Wl of a 32-k K-tile, 3 MFMAs per block (Wl Ah + Wh Al + Wh Ah, lo*lo dropped):
+//               24 fragment reads for 96 MFMAs per wave and K-tile (the 16-wave kernel: 32 for 96)
+// Prefetch per K-tile u: LOAD 0 stages A-plane 0 of tile u+1, LOAD 1 A-plane 1 of u+1 (their buffer has been idle since tile
+// u-1), LOAD 2 / 3 the two W planes of tile u+2 (tile u's W planes are dead after every wave's LOAD 0); ONE counted wait per
+// K-tile, vmcnt(4) at the end of LOAD 3 (tile u+1 complete, the two W planes of u+2 still in flight).
+template <bool X3>
+__global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __restrict__ A, int lda,
+                                                               const bf16_t* __restrict__ W, int ldw, int M, int N,
+                                                               int K, GemmEpi e, int GM) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const int grp_ = wu >> 2, wq = wu & 3;
+  const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
+  int tm, tn;
+  tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
+  const int m0 = tm * PPM, n0 = tn * PPN;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // staging through buffer descriptors: wave-uniform base in SGPRs, one 32-bit byte offset per lane (computed once), the
+  // K position as the scalar offset -- no 64-bit address arithmetic per DMA and half the address payload of global_load_lds
+  unsigned vA0, vA1, vW0, vW1;
+  {
+    const int rl = wid * 32 + (lane >> 2);
+    const int c = pp_swz(rl, lane & 3);
+    int ra0 = m0 + rl, ra1 = m0 + rl + 16; ra0 = ra0 < M ? ra0 : M - 1; ra1 = ra1 < M ? ra1 : M - 1;
+    int rw0 = n0 + rl, rw1 = n0 + rl + 16; rw0 = rw0 < N ? rw0 : N - 1; rw1 = rw1 < N ? rw1 : N - 1;
+    vA0 = (unsigned)(((size_t)ra0 * lda + c * 8) * 2); vA1 = (unsigned)(((size_t)ra1 * lda + c * 8) * 2);
+    vW0 = (unsigned)(((size_t)rw0 * ldw + c * 8) * 2); vW1 = (unsigned)(((size_t)rw1 * ldw + c * 8) * 2);
+  }
+  const size_t bytesA = (size_t)M * lda * 2, bytesW = (size_t)N * ldw * 2;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(bytesA > 0xfffffff0u ? 0xfffffff0u : bytesA), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)(bytesW > 0xfffffff0u ? 0xfffffff0u : bytesW), 0x00020000);
+  char* const sdst = smem + wu * 2048;
+  constexpr int KT = X3 ? 32 : 64;                 // k per K-tile
+  const int pl1 = X3 ? K : 32;                      // element offset of an operand's second plane
+#define PPM_STAGE(t, pl)                                                                                       \
+  {                                                                                                            \
+    char* d_ = sdst + ((t) & 1) * PP_TILE + (pl) * PP_PLANE;                                                   \
+    const int ko_ = ((t) * KT + (((pl) & 1) ? pl1 : 0)) * 2;                                                   \
+    if ((pl) < 2) {                                                                                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(d_), 16, vA0, ko_, 0, 0);                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(d_ + 1024), 16, vA1, ko_, 0, 0);                   \
+    } else {                                                                                                   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(d_), 16, vW0, ko_, 0, 0);                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(d_ + 1024), 16, vW1, ko_, 0, 0);                   \
+    }                                                                                                          \
+  }
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = K / KT;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  int offA[8], offW[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int row = grp_ * 128 + i * 16 + l15; offA[i] = row * 64 + pp_swz(row, l4) * 16; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int row = wq * 64 + j * 16 + l15; offW[j] = 2 * PP_PLANE + row * 64 + pp_swz(row, l4) * 16; }
+
+  PPM_STAGE(0, 0) PPM_STAGE(0, 1) PPM_STAGE(0, 2) PPM_STAGE(0, 3)
+  if (nk > 1) { PPM_STAGE(1, 2) PPM_STAGE(1, 3) }
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp_ == 1) __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 w0[4], w1[4], a0[2], a1[2];       // plane-0 / plane-1 fragments
+#define PPM_PHASE(st, q, PF_ON, PF_T, PF_PL, VW)                                                               \
+  {                                                                                                            \
+    if ((q) == 0) {                                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+        w0[j] = *reinterpret_cast<const bf16x8*>((st) + offW[j]);                                              \
+        w1[j] = *reinterpret_cast<const bf16x8*>((st) + offW[j] + PP_PLANE);                                   \
+      }                                                                                                        \
+    }                                                                                                          \
+    _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                         \
+      a0[ii] = *reinterpret_cast<const bf16x8*>((st) + offA[2 * (q) + ii]);                                    \
+      a1[ii] = *reinterpret_cast<const bf16x8*>((st) + offA[2 * (q) + ii] + PP_PLANE);                         \
+    }                                                                                                          \
+    if (PF_ON) PPM_STAGE(PF_T, PF_PL)                                                                          \
+    if ((VW) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
+    else if ((VW) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                           \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+        f32x4 c_ = acc[2 * (q) + ii][j];                                                                       \
+        if (X3) {                                                                                              \
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], a0[ii], c_, 0, 0, 0);   /* Wl Ah: small terms first */ \
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], a1[ii], c_, 0, 0, 0);   /* Wh Al */              \
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], a0[ii], c_, 0, 0, 0);   /* Wh Ah */              \
+        } else {                                                                                               \
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], a0[ii], c_, 0, 0, 0);   /* k 0..31 */            \
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], a1[ii], c_, 0, 0, 0);   /* k 32..63 */           \
+        }                                                                                                      \
+        acc[2 * (q) + ii][j] = c_;                                                                             \
+      }                                                                                                        \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  }
+
+  int u = 0;
+  for (; u + 2 < nk; ++u) {
+    const char* st = smem + (u & 1) * PP_TILE;
+    PPM_PHASE(st, 0, true, u + 1, 0, -1)
+    PPM_PHASE(st, 1, true, u + 1, 1, -1)
+    PPM_PHASE(st, 2, true, u + 2, 2, -1)
+    PPM_PHASE(st, 3, true, u + 2, 3, 4)           // tile u + 1 complete; the two W planes of u + 2 in flight
+  }
+  if (u + 1 < nk) {
+    const char* st = smem + (u & 1) * PP_TILE;
+    PPM_PHASE(st, 0, true, u + 1, 0, -1)
+    PPM_PHASE(st, 1, true, u + 1, 1, -1)
+    PPM_PHASE(st, 2, false, 0, 0, -1)
+    PPM_PHASE(st, 3, false, 0, 0, 0)
+    ++u;
+  }
+  {
+    const char* st = smem + (u & 1) * PP_TILE;
+    PPM_PHASE(st, 0, false, 0, 0, -1)
+    PPM_PHASE(st, 1, false, 0, 0, -1)
+    PPM_PHASE(st, 2, false, 0, 0, -1)
+    PPM_PHASE(st, 3, false, 0, 0, -1)
+  }
+  if (grp_ == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  constexpr int PITCH = PPN * 4 + 16;
+  const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row_l = grp_ * 64 + ii * 16 + l15;
+        const int col = wq * 64 + j * 16 + 4 * l4;
+        const f32x4 a = acc[pass * 4 + ii][j];
+        *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+    __syncthreads();
+    drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid,
+                              [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+  }
+}
+
 static constexpr int LDSPP = (128 * (PPN * 4 + 16)) > 2 * PP_TILE ? (128 * (PPN * 4 + 16)) : 2 * PP_TILE;
 
 // K % 64 == 0, K >= 64
@@ -195,9 +342,46 @@ int launch_gemm_bf16_pp(const bf16_t* A, int lda, const bf16_t* W, int ldw, int 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
     attr_set[dev] = true;
   }
-  static const char* gme = getenv("DINODET_GEMM_GM");
-  const int gm = gme ? atoi(gme) : 4;
+  const int gm = gemm_tile_mode();
   const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
   hipLaunchKernelGGL(gemm_pp_256x256_kernel, dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+static void ppm_attr() {
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
+    attr_set[dev] = true;
+  }
+}
+
+// plain bf16 on the m-phased ping-pong kernel: K % 64 == 0
+int launch_gemm_bf16_ppm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % PPK != 0) return 2;
+  if (N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || e.ldc % 4 != 0) return 2;
+  if (e.resid && e.ldr % 4 != 0) return 2;
+  if (!e.out_f32 && !e.out_bf16) return 2;
+  ppm_attr();
+  const int gm = gemm_tile_mode();
+  const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
+  hipLaunchKernelGGL(gemm_ppm_256x256_kernel<false>, dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// split product on pair-layout operands (same contract as launch_gemm_x3): K % 32 == 0
+int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0) return 1;
+  if (K % 32 != 0 || N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || lda < 2 * K || ldw < 2 * K) return 2;
+  if (e.out_f32 && e.ldc % 4 != 0) return 2;
+  if (e.resid && e.ldr % 4 != 0) return 2;
+  if (!e.out_f32 && !e.out_bf16) return 2;
+  ppm_attr();
+  const int gm = gemm_tile_mode();
+  const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
+  hipLaunchKernelGGL(gemm_ppm_256x256_kernel<true>, dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -34,42 +34,35 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
   const int tiles_m = (M + X3M - 1) / X3M, tiles_n = (N + X3N - 1) / X3N;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   int tm, tn;
-  {
-    const int per_group = GM * tiles_n;
-    const int grp = bid / per_group, first_m = grp * GM;
-    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-    const int in_g = bid - grp * per_group;
-    tm = first_m + in_g % gsz;
-    tn = in_g / gsz;
-  }
+  tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
   const int m0 = tm * X3M, n0 = tn * X3N;
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  // per K-tile a wave issues ONE 16-row piece of each plane (16 waves x 16 rows = 256)
-  const bf16_t* gA; const bf16_t* gW;
+  // per K-tile a wave issues ONE 16-row piece of each plane (16 waves x 16 rows = 256), through buffer descriptors: the base in
+  // SGPRs, one 32-bit byte offset per lane computed once, the K position as the scalar offset (no per-DMA 64-bit address math)
+  unsigned vA, vW;
   {
     const int rl = wid * 16 + (lane >> 2);
     const int c = x3_swz(rl, lane & 3);
     int ra = m0 + rl; ra = ra < M ? ra : M - 1;
     int rw = n0 + rl; rw = rw < N ? rw : N - 1;
-    gA = A2 + (size_t)ra * lda + c * 8;
-    gW = W2 + (size_t)rw * ldw + c * 8;
+    vA = (unsigned)(((size_t)ra * lda + c * 8) * 2);
+    vW = (unsigned)(((size_t)rw * ldw + c * 8) * 2);
   }
+  const size_t bytesA = (size_t)M * lda * 2, bytesW = (size_t)N * ldw * 2;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A2, 0, (int)(bytesA > 0xfffffff0u ? 0xfffffff0u : bytesA), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)W2, 0, (int)(bytesW > 0xfffffff0u ? 0xfffffff0u : bytesW), 0x00020000);
   const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const int pl1b = (PLAIN ? 32 : K) * 2;
 #define STAGE_X3(slot_, k0)                                                                                \
   {                                                                                                        \
     char* s_ = smem + (slot_) * X3_STAGE + wu * 1024;                                                      \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA + (k0)), (lptr_t)(s_), 16, 0, 0);                         \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA + (PLAIN ? 32 : K) + (k0)), (lptr_t)(s_ + X3_PLANE), 16, 0, 0); \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gW + (k0)), (lptr_t)(s_ + 2 * X3_PLANE), 16, 0, 0);          \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gW + (PLAIN ? 32 : K) + (k0)), (lptr_t)(s_ + 3 * X3_PLANE), 16, 0, 0); \
+    const int kb_ = (k0) * 2;                                                                              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(s_), 16, vA, kb_, 0, 0);                         \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(s_ + X3_PLANE), 16, vA, kb_ + pl1b, 0, 0);       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(s_ + 2 * X3_PLANE), 16, vW, kb_, 0, 0);          \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(s_ + 3 * X3_PLANE), 16, vW, kb_ + pl1b, 0, 0);   \
   }
   f32x4 acc[4][4];
 #pragma unroll
@@ -136,6 +129,17 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
   }
 }
 
+// tile-order mode of the 256x256 kernels (gemm_epi.h tile_map): DINODET_GEMM_GM = group depth, DINODET_GEMM_ORDER = bit 0 reverse,
+// bit 1 chunked (tuning switches, read per call)
+int gemm_tile_mode() {
+  const char* g = getenv("DINODET_GEMM_GM");
+  const char* o = getenv("DINODET_GEMM_ORDER");
+  int gm = g ? atoi(g) : 4;
+  if (gm < 1 || gm > 64) gm = 4;
+  const int ord = o ? atoi(o) : 2;        // default: time-ordered map (measured +5 % on QKV / fc2, +3-5 % on out-proj at M = 87680)
+  return gm | ((ord & 1) ? 0x100 : 0) | ((ord & 2) ? 0x200 : 0);
+}
+
 static constexpr int LDSX3 = (128 * (X3N * 4 + 16)) > X3_SLOTS * X3_STAGE ? (128 * (X3N * 4 + 16)) : X3_SLOTS * X3_STAGE;
 
 // A2 [M, lda >= 2K], W2 [N, ldw >= 2K]: pair layout; K % 32 == 0
@@ -146,14 +150,21 @@ int launch_gemm_x3(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, 
   if (e.out_f32 && e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
+  {
+    // the 8-wave ping-pong kernel (gemm_pp.hip) wherever a workgroup's K loop or column count is long enough to pay for its
+    // 512-thread epilogue: measured at M = 87680 against the 16-wave kernel below -- QKV 400 vs 378, fc1 376 vs 363, fc2 406 vs 371
+    // TFLOP/s algorithmic; out-proj (N = K = 768) 276 vs 293, so that one stays.  DINODET_X3_TILE = p / w forces either.
+    const char* v = getenv("DINODET_X3_TILE");
+    const bool pp = v ? v[0] == 'p' : (M >= 4096 && (N >= 1536 || K >= 2048));
+    if (pp) return launch_gemm_x3_pp(A2, lda, W2, ldw, M, N, K, e, s);
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
     attr_set = true;
   }
-  static const char* gme = getenv("DINODET_GEMM_GM");
-  const int gm = gme ? atoi(gme) : 4;
+  const int gm = gemm_tile_mode();
   const int tiles = ((M + X3M - 1) / X3M) * ((N + X3N - 1) / X3N);
   hipLaunchKernelGGL(gemm_x3_256x256_kernel<false>, dim3(tiles), dim3(1024), LDSX3, s, A2, lda, W2, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
@@ -167,8 +178,7 @@ int launch_gemm_bf16_k64(const bf16_t* A, int lda, const bf16_t* W, int ldw, int
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
     attr_set = true;
   }
-  static const char* gme = getenv("DINODET_GEMM_GM");
-  const int gm = gme ? atoi(gme) : 4;
+  const int gm = gemm_tile_mode();
   const int tiles = ((M + X3M - 1) / X3M) * ((N + X3N - 1) / X3N);
   hipLaunchKernelGGL(gemm_x3_256x256_kernel<true>, dim3(tiles), dim3(1024), LDSX3, s, A, lda, W, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;

@@ -39,7 +39,7 @@ def _taps(m, B, N, bb, dc):
     return t
 
 
-K_BF16 = 1.5    # HIP-vs-fp32 distance allowed, in units of the bf16-faithful oracle's own distance to fp32
+K_BF16 = 1.3    # HIP-vs-fp32 distance allowed, in units of the bf16-faithful oracle's own distance to fp32
 
 # parity-gated modes: "fp32" (exact-fp32 MFMA / VALU) and "bf16x3" (split products on the bf16 MFMA kernels, ~1e-5)
 GATED = ["fp32", "bf16x3"]
@@ -528,7 +528,7 @@ def test_full_depth_configs_throughput_modes(G, variant, precision):
     e0 = rel_err(r[f"block{blocks[0]}"], emu[p + f"block{blocks[0]}_probe"])
     print(f"{variant} {precision} block0 vs faithful oracle: {e0:.2e}")
     assert e0 < (4e-3 if precision == "bf16" else 4e-2)          # one bf16 ulp = 3.9e-3; one e4m3 step = 6e-2
-    K = 1.5
+    K = 1.3
     for b in blocks[1:]:
         got, floor = rel_l2(r[f"block{b}"], g[f"block{b}_probe"]), rel_l2(emu[p + f"block{b}_probe"], g[f"block{b}_probe"])
         print(f"{variant} {precision} block{b}: rel-L2 vs the reference {got:.2e} (faithful oracle {floor:.2e})")

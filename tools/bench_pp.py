@@ -14,6 +14,9 @@ from dinov2_od_amd import _native as nat
 
 
 def set_variant(v):
+    if v.startswith("o"):                      # tile-order A/B: "o0".."o3"
+        os.environ["DINODET_GEMM_ORDER"] = v[1:]
+        return
     if v == "default":
         os.environ.pop("DINODET_GEMM_TILE", None)
     else:
@@ -28,11 +31,15 @@ def main():
     ap.add_argument("--variants", default="default,p")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--producer", action="store_true", help="re-write A (rows 0 -> M, as a producer kernel would) right before every timed GEMM, which is timed alone: the in-forward cache state instead of a warm one")
+    ap.add_argument("--orders", default="", help="comma list of DINODET_GEMM_ORDER values to A/B (variants then must be one entry)")
     ap.add_argument("--lda0", action="store_true", help="every A row aliases row 0 (A traffic becomes cache hits): isolates the A-panel miss cost")
     ap.add_argument("--zeros", action="store_true", help="all-zero operands (clock stays high: the DVFS bound)")
     ap.add_argument("--noout", action="store_true", help="ldc = 0: every output row aliases row 0 (output / residual traffic becomes cache hits)")
     a = ap.parse_args()
     variants = a.variants.split(",")
+    if a.orders:
+        variants = ["o" + o for o in a.orders.split(",")]
     L = nat.lib()
     dev = torch.device("cuda:0")
     M, D = a.rows or a.batch * 1370, a.hidden
@@ -70,11 +77,24 @@ def main():
                 ref = got
             devs[v] = float((got - ref).abs().max() / ref.abs().max())
         times = {v: [] for v in variants}
+        A_src = A.clone() if a.producer else None
         for _ in range(a.rounds):
             for v in variants:
                 set_variant(v)
                 run()
                 torch.cuda.synchronize()
+                if a.producer:
+                    tot = 0.0
+                    for _ in range(a.iters):
+                        A.copy_(A_src)                         # the producer: writes A front to back
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        run()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        tot += e0.elapsed_time(e1)
+                    times[v].append(tot / a.iters * 1e-3)
+                    continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.iters):
