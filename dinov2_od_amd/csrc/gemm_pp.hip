@@ -379,9 +379,12 @@ int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int 
   if (e.out_f32 && e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
+  GemmEpi e2 = e;
+  if (getenv("DINODET_DEBUG_NOOUT")) { e2.ldc = 0; e2.ldr = 0; }   // tuning only: every output row aliases row 0
   ppm_attr();
+  if (getenv("DINODET_DEBUG_LDA0")) lda = 0;      // tuning only: every A row aliases row 0 (A traffic becomes cache hits)
   const int gm = gemm_tile_mode();
   const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
-  hipLaunchKernelGGL(gemm_ppm_256x256_kernel<true>, dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e, gm);
+  hipLaunchKernelGGL(gemm_ppm_256x256_kernel<true>, dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e2, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

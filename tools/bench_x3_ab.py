@@ -17,6 +17,7 @@ def pair(x):
     nat.check(L.dod_op_split_pair(nat.ptr(x), x.stride(0), x.shape[0], x.shape[1], nat.ptr(out), nat.stream_ptr())); return out
 for name, n, k, layout, act, resid in (("qkv", 3 * D, D, 2, 0, False), ("proj", D, D, 0, 0, True), ("fc1", 4 * D, D, 2, 2, False), ("fc2", D, 4 * D, 0, 0, True)):
     A2 = pair((torch.randn(M, k, generator=g) * 0.5).to(dev)); W2 = pair((torch.randn(n, k, generator=g) * 0.05).to(dev))
+    if os.environ.get("X3_ZERO"): A2.zero_(); W2.zero_()
     bias = torch.randn(n, generator=g).to(dev); x0 = torch.randn(M, n, generator=g).to(dev) if resid else None
     x = x0.clone() if resid else None
     out = x if resid else torch.empty(M, 2 * n if layout == 2 else n, dtype=torch.bfloat16 if layout else torch.float32, device=dev)
