@@ -35,6 +35,16 @@ class DodDetection(C.Structure):
     _fields_ = [("image_id", C.c_int64), ("category_id", C.c_int32), ("query", C.c_int32), ("bbox", C.c_float * 4),
                 ("score", C.c_float), ("reserved", C.c_int32)]
 
+# struct dod_dec_train_params: 31 device pointers in this order (the same struct carries the gradient accumulators)
+DEC_TRAIN_FIELDS = ["query_embed", "class_w", "class_b", "bb0_w", "bb0_b", "bb2_w", "bb2_b", "in_proj_w", "in_proj_b", "out_proj_w",
+                    "out_proj_b", "norm1_w", "norm1_b", "norm2_w", "norm2_b", "norm3_w", "norm3_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
+                    "refp_w", "refp_b", "off_w", "off_b", "aw_w", "aw_b", "vp_w", "vp_b", "op_w", "op_b"]
+
+
+class DodDecTrainParams(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in DEC_TRAIN_FIELDS]
+
+
 # name -> (restype, argtypes): every symbol include/dinodet.h declares
 SYMBOLS = {
     "dod_create": (_I, [C.POINTER(DodConfig), C.POINTER(_P)]),
@@ -69,6 +79,11 @@ SYMBOLS = {
     "dod_postprocess": (_I, [_P, _I, _I, _I, _P, _F, _P, C.c_int64, _P, _P, _SZ, _P]),
     "dod_preprocess": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "dod_match_cost": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P, _P]),
+    "dod_decoder_train_tape_bytes": (_SZ, [C.POINTER(DodConfig), _I, _I]),
+    "dod_decoder_train_workspace_bytes": (_SZ, [C.POINTER(DodConfig), _I, _I]),
+    "dod_decoder_train_forward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _F, C.c_uint64, _P, _P, _SZ, _P, _SZ, _P]),
+    "dod_decoder_train_backward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _F, C.c_uint64, _P, _P, _SZ, _P, _P, _P, _SZ, _P]),
+    "dod_decoder_train_last_error": (C.c_char_p, []),
     "dod_debug_gemm_stamps": (_I, [_P]),
     "dod_debug_attn_stamps": (_I, [_P]),
     "dod_debug_mfma_peak": (_I, [_I, _I, _I, _P, _P]),

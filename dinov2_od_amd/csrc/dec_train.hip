@@ -1,0 +1,681 @@
+// Native training step of the decoder + heads (first slice): train-mode forward with a tape and
+// the backward of DETRDecoder.forward (detr_decoder.py:47-83) over the weight-tied DeformableDecoderLayer
+// (deformable_attention.py:215-268, :284) -- what `loss.backward()` at train.py:1101 computes for the decoder, the heads and
+// d(memory) (which then flows into the projection / LoRA blocks).  fp32 throughout (master weights, exact-fp32 MFMA GEMMs).
+//
+//   forward  : query tiling -> per layer { MHA self-attention (dropout on the probabilities, nn.MultiheadAttention) -> +dropout1
+//              -> LN1 -> sigmoid reference points, offsets, point weights -> bilinear gather -> output_proj -> +dropout2 -> LN2
+//              -> linear1 -> ReLU -> dropout3 -> linear2 -> +dropout4 -> LN3 } -> class / box heads.
+//   backward : the exact adjoint of each step; weight gradients ACCUMULATE (the layers share one set of weights, and the
+//              caller may accumulate over micro-batches); d(values) is a float-atomic scatter-add of the same four corners the
+//              forward gathered (floor / clamp carry no gradient; torch.clamp passes it inside [0, 1] inclusive).
+// Linear backward runs on the fp32 MFMA GEMM of the forward (gemm_f32.hip: C = A W^T): dX = dY (W^T)^T and dW = dY^T (X^T)^T on
+// transposed, zero-padded copies.  Dropout masks come from a counter-based hash of (seed, site, element): the backward
+// regenerates them, nothing but activations is taped.
+#include "dod_common.h"
+#include "../../include/dinodet.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace {
+
+inline size_t up4(size_t x) { return (x + 3) & ~(size_t)3; }
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ------------------------------------------------------------------------------------------------ RNG
+__device__ __forceinline__ float u01(unsigned long long key, unsigned long long idx) {
+  unsigned long long z = key + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__host__ __device__ inline unsigned long long site_key(unsigned long long seed, int layer, int site) {
+  return seed * 0xD1342543DE82EF95ull + (unsigned long long)(layer * 8 + site + 1) * 0x9E3779B97F4A7C15ull;
+}
+
+// ------------------------------------------------------------------------------------------------ small kernels
+// dst[c][r] = src[r][c]; dst has ld_dst >= rows columns, columns rows..ld_dst-1 are zeroed
+__global__ void transpose_pad_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, float* __restrict__ dst, int ld_dst) {
+  __shared__ float t[32][33];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: 8 rows per pass
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    t[i][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < ld_dst) dst[(size_t)c * ld_dst + r] = t[tx][i];
+  }
+}
+int transpose_pad(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t s) {
+  dim3 g((ld_dst + 31) / 32, (cols + 31) / 32);
+  hipLaunchKernelGGL(transpose_pad_kernel, g, dim3(256), 0, s, src, ld_src, rows, cols, dst, ld_dst);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// dst[c] += sum_r src[r][c]
+__global__ void colsum_kernel(const float* __restrict__ src, int ld, int rows, int cols, float* __restrict__ dst) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < cols)
+    for (int r = blockIdx.y * 4 + w; r < rows; r += gridDim.y * 4) acc += src[(size_t)r * ld + c];
+  __shared__ float red[4][64];
+  red[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && c < cols) atomicAdd(dst + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+int colsum_add(const float* src, int ld, int rows, int cols, float* dst, hipStream_t s) {
+  int gy = (rows + 63) / 64; gy = gy < 1 ? 1 : (gy > 128 ? 128 : gy);
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, gy), dim3(256), 0, s, src, ld, rows, cols, dst);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// out = a + keep(b) / (1 - p)   (p == 0: plain add); also used with a == nullptr (out = dropped b)
+__global__ void dropout_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n,
+                                   float p, unsigned long long key) {
+  const float inv = 1.0f / (1.0f - p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = b[i];
+    if (p > 0.f) v = u01(key, i) >= p ? v * inv : 0.f;
+    out[i] = a ? a[i] + v : v;
+  }
+}
+int dropout_add(const float* a, const float* b, float* out, size_t n, float p, unsigned long long key, hipStream_t s) {
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(dropout_add_kernel, dim3(blocks), dim3(256), 0, s, a, b, out, n, p, key);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+// g = dy * (y > 0 ? 1 : 0) [* dropout mask / (1 - p)]
+__global__ void relu_drop_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ g, size_t n, float p,
+                                     unsigned long long key) {
+  const float inv = 1.0f / (1.0f - p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = dy[i];
+    if (p > 0.f) v = u01(key, i) >= p ? v * inv : 0.f;
+    g[i] = y[i] > 0.f ? v : 0.f;
+  }
+}
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i];
+}
+int add_inplace(float* a, const float* b, size_t n, hipStream_t s) {
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, s, a, b, n);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+// dz[r][0..3] = dbox[r][0..3] * s (1 - s), s = the forward's sigmoid output
+__global__ void sigmoid_bwd4_kernel(const float* __restrict__ dbox, int ldd, const float* __restrict__ box, int ldb, float* __restrict__ dz, int rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * 4) return;
+  const int r = i >> 2, c = i & 3;
+  const float sg = box[(size_t)r * ldb + c];
+  dz[i] = dbox[(size_t)r * ldd + c] * sg * (1.0f - sg);
+}
+// dq[q][:] += sum_b d[b][q][:]
+__global__ void batch_sum_kernel(const float* __restrict__ d, float* __restrict__ dq, int B, size_t per) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += d[(size_t)b * per + i];
+    dq[i] += acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// x: the pre-norm input (t = residual + branch), dy: gradient of the LayerNorm output.  dx per row; dgamma / dbeta accumulated
+// per wave over its rows, then one float atomic per column and wave.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dy,
+                                                     float eps, int rows, int D, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  constexpr int MAXC = 16;                         // D <= 1024
+  float dg[MAXC], db[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) { dg[c] = 0.f; db[c] = 0.f; }
+  for (int r = wave; r < rows; r += nwaves) {
+    const float* xr = x + (size_t)r * D;
+    const float* dyr = dy + (size_t)r * D;
+    float xv[MAXC], gv[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) { const int k = c * 64 + lane; xv[c] = k < D ? xr[k] : 0.f; s += xv[c]; }
+    const float mu = wave_sum(s) / (float)D;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) { const int k = c * 64 + lane; const float d = k < D ? xv[c] - mu : 0.f; v += d * d; }
+    const float rstd = rsqrtf(wave_sum(v) / (float)D + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int k = c * 64 + lane;
+      if (k < D) {
+        const float xh = (xv[c] - mu) * rstd, d = dyr[k];
+        gv[c] = d * gamma[k];
+        xv[c] = xh;
+        s1 += gv[c]; s2 += gv[c] * xh;
+        dg[c] += d * xh; db[c] += d;
+      } else { gv[c] = 0.f; xv[c] = 0.f; }
+    }
+    s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+    float* dxr = dx + (size_t)r * D;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) { const int k = c * 64 + lane; if (k < D) dxr[k] = rstd * (gv[c] - s1 - xv[c] * s2); }
+  }
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int k = c * 64 + lane;
+    if (k < D) { atomicAdd(dgamma + k, dg[c]); atomicAdd(dbeta + k, db[c]); }
+  }
+}
+int ln_bwd(const float* x, const float* gamma, const float* dy, float eps, int rows, int D, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
+  if (D > 1024) return 2;
+  int blocks = (rows + 15) / 16; blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, gamma, dy, eps, rows, D, dx, dgamma, dbeta);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// ------------------------------------------------------------------------------------------------ multi-head self-attention (Q x Q)
+// nn.MultiheadAttention (deformable_attention.py:195, 233): softmax((q k^T) / sqrt(dh)), dropout on the probabilities, times v.
+// qkv [B*Q, 3*Dd] = [q | k | v], head h at columns h*dh.  One wave per (b, head, query row).
+#define MHA_MAXQ 1024
+__device__ __forceinline__ void mha_row_probs(const float* __restrict__ qkv, int ld, int b, int h, int i, int Q, int Dd, int dh, float scale,
+                                              float* __restrict__ sp, int lane) {
+  const float* qi = qkv + ((size_t)b * Q + i) * ld + h * dh;
+  float mx = -INFINITY;
+  for (int j = lane; j < Q; j += 64) {
+    const float* kj = qkv + ((size_t)b * Q + j) * ld + Dd + h * dh;
+    float acc = 0.f;
+    for (int d = 0; d < dh; d += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(qi + d), k4 = *reinterpret_cast<const float4*>(kj + d);
+      acc += a.x * k4.x + a.y * k4.y + a.z * k4.z + a.w * k4.w;
+    }
+    acc *= scale;
+    sp[j] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < Q; j += 64) { const float e = expf(sp[j] - mx); sp[j] = e; sum += e; }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < Q; j += 64) sp[j] *= inv;
+}
+
+__global__ __launch_bounds__(256) void mha_fwd_train_kernel(const float* __restrict__ qkv, int ld, float* __restrict__ out, int ldo, int B,
+                                                            int Q, int Hd, int Dd, int dh, float scale, float p, unsigned long long key) {
+  __shared__ float sP[4][MHA_MAXQ];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long item = (long)blockIdx.x * 4 + w;
+  if (item >= (long)B * Hd * Q) return;
+  const int i = (int)(item % Q);
+  const long bh = item / Q;
+  const int h = (int)(bh % Hd), b = (int)(bh / Hd);
+  float* sp = sP[w];
+  mha_row_probs(qkv, ld, b, h, i, Q, Dd, dh, scale, sp, lane);
+  if (p > 0.f) {
+    const float inv = 1.0f / (1.0f - p);
+    for (int j = lane; j < Q; j += 64) sp[j] = u01(key, (unsigned long long)item * Q + j) >= p ? sp[j] * inv : 0.f;
+  }
+  // O_i[d] = sum_j P_ij v_j[d]; lanes along d (two columns per lane when dh > 64)
+  const float* vb = qkv + (size_t)b * Q * ld + 2 * Dd + h * dh;
+  float o0 = 0.f, o1 = 0.f;
+  const bool d0 = lane < dh, d1 = lane + 64 < dh;
+  for (int j = 0; j < Q; ++j) {
+    const float pj = sp[j];
+    const float* vj = vb + (size_t)j * ld;
+    if (d0) o0 += pj * vj[lane];
+    if (d1) o1 += pj * vj[lane + 64];
+  }
+  float* op = out + ((size_t)b * Q + i) * ldo + h * dh;
+  if (d0) op[lane] = o0;
+  if (d1) op[lane + 64] = o1;
+}
+
+// row pass: dS[b,h,i,:], Pd[b,h,i,:] (dropped probabilities) to scratch, dq_i
+__global__ __launch_bounds__(256) void mha_bwd_row_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dO, int ldo,
+                                                          float* __restrict__ dqkv, float* __restrict__ dS, float* __restrict__ Pd, int B, int Q,
+                                                          int Hd, int Dd, int dh, float scale, float p, unsigned long long key) {
+  __shared__ float sP[4][MHA_MAXQ];
+  __shared__ float sD[4][MHA_MAXQ];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long item = (long)blockIdx.x * 4 + w;
+  if (item >= (long)B * Hd * Q) return;
+  const int i = (int)(item % Q);
+  const long bh = item / Q;
+  const int h = (int)(bh % Hd), b = (int)(bh / Hd);
+  float* sp = sP[w];
+  float* sd = sD[w];
+  mha_row_probs(qkv, ld, b, h, i, Q, Dd, dh, scale, sp, lane);
+  const float* doi = dO + ((size_t)b * Q + i) * ldo + h * dh;
+  const float inv = 1.0f / (1.0f - p);
+  float dot = 0.f;
+  for (int j = lane; j < Q; j += 64) {
+    const float* vj = qkv + ((size_t)b * Q + j) * ld + 2 * Dd + h * dh;
+    float acc = 0.f;
+    for (int d = 0; d < dh; d += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(doi + d), v4 = *reinterpret_cast<const float4*>(vj + d);
+      acc += a.x * v4.x + a.y * v4.y + a.z * v4.z + a.w * v4.w;
+    }
+    float keepf = 1.0f;
+    if (p > 0.f) keepf = u01(key, (unsigned long long)item * Q + j) >= p ? inv : 0.f;
+    const float dP = acc * keepf;          // d(loss) / d(P_ij) through the dropout
+    sd[j] = dP;
+    dot += dP * sp[j];
+    Pd[(size_t)item * Q + j] = sp[j] * keepf;
+  }
+  dot = wave_sum(dot);
+  for (int j = lane; j < Q; j += 64) {
+    const float ds = sp[j] * (sd[j] - dot);
+    sd[j] = ds;
+    dS[(size_t)item * Q + j] = ds;
+  }
+  // dq_i[d] = scale * sum_j dS_ij k_j[d]
+  const float* kb = qkv + (size_t)b * Q * ld + Dd + h * dh;
+  float q0 = 0.f, q1 = 0.f;
+  const bool d0 = lane < dh, d1 = lane + 64 < dh;
+  for (int j = 0; j < Q; ++j) {
+    const float ds = sd[j];
+    const float* kj = kb + (size_t)j * ld;
+    if (d0) q0 += ds * kj[lane];
+    if (d1) q1 += ds * kj[lane + 64];
+  }
+  float* dq = dqkv + ((size_t)b * Q + i) * ld + h * dh;
+  if (d0) dq[lane] = q0 * scale;
+  if (d1) dq[lane + 64] = q1 * scale;
+}
+// column pass: dk_j = scale * sum_i dS_ij q_i, dv_j = sum_i Pd_ij dO_i
+__global__ __launch_bounds__(256) void mha_bwd_col_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dO, int ldo,
+                                                          float* __restrict__ dqkv, const float* __restrict__ dS, const float* __restrict__ Pd,
+                                                          int B, int Q, int Hd, int Dd, int dh, float scale) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long item = (long)blockIdx.x * 4 + w;
+  if (item >= (long)B * Hd * Q) return;
+  const int j = (int)(item % Q);
+  const long bh = item / Q;
+  const int h = (int)(bh % Hd), b = (int)(bh / Hd);
+  const float* qb = qkv + (size_t)b * Q * ld + h * dh;
+  const float* dob = dO + (size_t)b * Q * ldo + h * dh;
+  const float* dsb = dS + (size_t)bh * Q * Q + j;
+  const float* pdb = Pd + (size_t)bh * Q * Q + j;
+  float k0 = 0.f, k1 = 0.f, v0 = 0.f, v1 = 0.f;
+  const bool d0 = lane < dh, d1 = lane + 64 < dh;
+  for (int i = 0; i < Q; ++i) {
+    const float ds = dsb[(size_t)i * Q], pd = pdb[(size_t)i * Q];
+    const float* qi = qb + (size_t)i * ld;
+    const float* di = dob + (size_t)i * ldo;
+    if (d0) { k0 += ds * qi[lane]; v0 += pd * di[lane]; }
+    if (d1) { k1 += ds * qi[lane + 64]; v1 += pd * di[lane + 64]; }
+  }
+  float* dk = dqkv + ((size_t)b * Q + j) * ld + Dd + h * dh;
+  float* dv = dqkv + ((size_t)b * Q + j) * ld + 2 * Dd + h * dh;
+  if (d0) { dk[lane] = k0 * scale; dv[lane] = v0; }
+  if (d1) { dk[lane + 64] = k1 * scale; dv[lane + 64] = v1; }
+}
+
+// ------------------------------------------------------------------------------------------------ deformable gather backward
+// Adjoint of deform_sample_kernel (deform.hip; deformable_attention.py:101-174).  One wave per (b, q, head), lanes along dh.
+// dproj must be zero on entry (the two reference-logit columns are shared by all heads: float atomics); dvalues accumulates.
+__global__ __launch_bounds__(256) void deform_bwd_kernel(const float* __restrict__ proj, int ldp, const float* __restrict__ values,
+                                                         const float* __restrict__ dout, int B, int Q, int N, int Hd, int P, int dh, int h,
+                                                         int w, float* __restrict__ dproj, float* __restrict__ dvalues) {
+  const int lane = threadIdx.x & 63;
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (long)B * Q * Hd) return;
+  const int hd = (int)(item % Hd);
+  const long bq = item / Hd;
+  const int b = (int)(bq / Q);
+  const float* pr = proj + (size_t)bq * ldp;
+  float* dpr = dproj + (size_t)bq * ldp;
+  const float refx = sigmoidf_(pr[0]), refy = sigmoidf_(pr[1]);
+  const float* off = pr + 2 + hd * P * 2;
+  const float* awl = pr + 2 + Hd * P * 2 + hd * P;
+  float mx = -INFINITY;
+  for (int p = 0; p < P; ++p) mx = fmaxf(mx, awl[p]);
+  float aw[8], den = 0.f;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) { aw[p] = p < P ? expf(awl[p] - mx) : 0.f; den += aw[p]; }
+  const int Dd = Hd * dh;
+  const float* vb = values + (size_t)b * N * Dd + hd * dh;
+  float* dvb = dvalues + (size_t)b * N * Dd + hd * dh;
+  const float* g = dout + (size_t)bq * Dd + hd * dh;
+  const bool d0ok = lane < dh, d1ok = lane + 64 < dh;
+  const float g0 = d0ok ? g[lane] : 0.f, g1 = d1ok ? g[lane + 64] : 0.f;
+  float da[8];
+  float drefx = 0.f, drefy = 0.f;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    da[p] = 0.f;
+    if (p < P) {
+      const float sx = refx + off[2 * p], sy = refy + off[2 * p + 1];
+      float lx = fminf(fmaxf(sx, 0.f), 1.f), ly = fminf(fmaxf(sy, 0.f), 1.f);
+      lx = lx * (float)(w - 1);
+      ly = ly * (float)(h - 1);
+      int x0 = (int)floorf(lx), y0 = (int)floorf(ly);
+      int x1 = x0 + 1, y1 = y0 + 1;
+      x0 = min(max(x0, 0), w - 1); x1 = min(max(x1, 0), w - 1);
+      y0 = min(max(y0, 0), h - 1); y1 = min(max(y1, 0), h - 1);
+      const float wx1 = lx - (float)x0, wx0 = 1.0f - wx1;
+      const float wy1 = ly - (float)y0, wy0 = 1.0f - wy1;
+      const float a = aw[p] / den;
+      const size_t i00 = (size_t)(y0 * w + x0) * Dd, i01 = (size_t)(y1 * w + x0) * Dd, i10 = (size_t)(y0 * w + x1) * Dd, i11 = (size_t)(y1 * w + x1) * Dd;
+      // <g, V_c> per corner
+      float p00 = 0.f, p01 = 0.f, p10 = 0.f, p11 = 0.f;
+      if (d0ok) { p00 += g0 * vb[i00 + lane]; p01 += g0 * vb[i01 + lane]; p10 += g0 * vb[i10 + lane]; p11 += g0 * vb[i11 + lane]; }
+      if (d1ok) { p00 += g1 * vb[i00 + lane + 64]; p01 += g1 * vb[i01 + lane + 64]; p10 += g1 * vb[i10 + lane + 64]; p11 += g1 * vb[i11 + lane + 64]; }
+      p00 = wave_sum(p00); p01 = wave_sum(p01); p10 = wave_sum(p10); p11 = wave_sum(p11);
+      const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;
+      da[p] = p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11;      // d out / d a_p
+      // corner scatter: dV_c += a w_c g
+      if (d0ok) {
+        atomicAdd(dvb + i00 + lane, a * w00 * g0); atomicAdd(dvb + i01 + lane, a * w01 * g0);
+        atomicAdd(dvb + i10 + lane, a * w10 * g0); atomicAdd(dvb + i11 + lane, a * w11 * g0);
+      }
+      if (d1ok) {
+        atomicAdd(dvb + i00 + lane + 64, a * w00 * g1); atomicAdd(dvb + i01 + lane + 64, a * w01 * g1);
+        atomicAdd(dvb + i10 + lane + 64, a * w10 * g1); atomicAdd(dvb + i11 + lane + 64, a * w11 * g1);
+      }
+      // bilinear weights -> pixel coordinates -> normalised location (clamp passes the gradient inside [0, 1] inclusive)
+      const float dwx0 = a * (p00 * wy0 + p01 * wy1), dwx1 = a * (p10 * wy0 + p11 * wy1);
+      const float dwy0 = a * (p00 * wx0 + p10 * wx1), dwy1 = a * (p01 * wx0 + p11 * wx1);
+      float dsx = (dwx1 - dwx0) * (float)(w - 1), dsy = (dwy1 - dwy0) * (float)(h - 1);
+      if (!(sx >= 0.f && sx <= 1.f)) dsx = 0.f;
+      if (!(sy >= 0.f && sy <= 1.f)) dsy = 0.f;
+      if (lane == 0) { dpr[2 + hd * P * 2 + 2 * p] = dsx; dpr[2 + hd * P * 2 + 2 * p + 1] = dsy; }
+      drefx += dsx; drefy += dsy;
+    }
+  }
+  // point-weight softmax backward
+  float dotp = 0.f;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) if (p < P) dotp += (aw[p] / den) * da[p];
+  if (lane == 0) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) if (p < P) dpr[2 + Hd * P * 2 + hd * P + p] = (aw[p] / den) * (da[p] - dotp);
+    atomicAdd(dpr + 0, drefx * refx * (1.0f - refx));        // sigmoid of the reference logits
+    atomicAdd(dpr + 1, drefy * refy * (1.0f - refy));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ orchestration
+std::string g_terr;
+int tfail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_terr = buf;
+  return code;
+}
+#define TK(x) do { int r_ = (x); if (r_) return tfail(r_ == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "decoder train: %s failed (%d)", #x, r_); } while (0)
+#define TH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return tfail(DOD_ERR_HIP, "decoder train: %s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+struct Dims { int B, N, Q, Dd, Hd, P, F, C, L, dh, ncat, ncp, BQ, M, fh, fw; };
+bool make_dims(const dod_config* c, int B, int N, Dims* d) {
+  if (!c || B <= 0 || N <= 0 || !c->use_deformable) return false;
+  d->B = B; d->N = N; d->Q = c->num_queries; d->Dd = c->dec_hidden; d->Hd = c->dec_heads; d->P = c->n_points; d->F = c->dim_feedforward;
+  d->C = c->num_classes; d->L = c->dec_layers; d->dh = d->Dd / d->Hd; d->ncat = 2 + 3 * d->Hd * d->P; d->ncp = (int)up4(d->ncat);
+  d->BQ = B * d->Q; d->M = B * N;
+  if (d->Dd % d->Hd || d->dh > 128 || d->dh % 4 || d->Dd % 4 || d->F % 4 || (d->Dd / 2) % 4 || d->Dd > 1024 || d->Q > MHA_MAXQ || d->P > 8 || d->P < 1) return false;
+  int s = 1; while ((s + 1) * (s + 1) <= N) ++s;          // (h, w) of deformable_attention.py:241-256
+  d->fh = s; d->fw = s;
+  if (s * s != N) for (int i = s; i > 0; --i) if (N % i == 0) { d->fh = i; d->fw = N / i; break; }
+  return true;
+}
+
+// tape layout (floats)
+struct Tape {
+  float *values, *hs, *hb, *boxes;
+  struct Layer { float *tgt_in, *qkv, *att, *t1, *tgt1, *proj, *samp, *t2, *tgt2, *hid, *t3; } l[64];
+};
+size_t carve_tape(const Dims& d, void* base, Tape* t) {
+  size_t off = 0;
+  auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr; off += al256(n * 4); return p; };
+  const size_t BQ = d.BQ, Dd = d.Dd;
+  Tape tt;
+  tt.values = take((size_t)d.M * Dd); tt.hs = take(BQ * Dd); tt.hb = take(BQ * (Dd / 2)); tt.boxes = take(BQ * 4);
+  for (int j = 0; j < d.L; ++j) {
+    auto& L = tt.l[j];
+    L.tgt_in = take(BQ * Dd); L.qkv = take(BQ * 3 * Dd); L.att = take(BQ * Dd); L.t1 = take(BQ * Dd); L.tgt1 = take(BQ * Dd);
+    L.proj = take(BQ * d.ncp); L.samp = take(BQ * Dd); L.t2 = take(BQ * Dd); L.tgt2 = take(BQ * Dd); L.hid = take(BQ * (size_t)d.F); L.t3 = take(BQ * Dd);
+  }
+  if (t) *t = tt;
+  return off;
+}
+
+struct Scratch {
+  float *y, *cat_w, *cat_b;                       // forward: branch output, fused [ref | offsets | weights] linear
+  // backward
+  float *dtgt, *dt, *dbr, *dbig, *dproj, *dcat_w, *dcat_b, *dqkv, *dS, *Pd, *dvalues, *dhb, *dz, *padY, *tY, *tX, *wT;
+};
+size_t carve_scratch(const Dims& d, void* base, Scratch* sc) {
+  size_t off = 0;
+  auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr; off += al256(n * 4); return p; };
+  const size_t BQ = d.BQ, Dd = d.Dd, F = d.F, M = d.M;
+  const size_t maxcols = (size_t)(3 * Dd > F ? 3 * Dd : F);           // widest activation of the query side
+  const size_t rows_max = M > BQ ? M : BQ;
+  Scratch s;
+  s.y = take(BQ * maxcols); s.cat_w = take((size_t)d.ncp * Dd); s.cat_b = take(d.ncp);
+  s.dtgt = take(BQ * Dd); s.dt = take(BQ * Dd); s.dbr = take(BQ * Dd); s.dbig = take(BQ * maxcols); s.dproj = take(BQ * d.ncp);
+  s.dcat_w = take((size_t)d.ncp * Dd); s.dcat_b = take(d.ncp); s.dqkv = take(BQ * 3 * Dd);
+  s.dS = take((size_t)d.B * d.Hd * d.Q * d.Q); s.Pd = take((size_t)d.B * d.Hd * d.Q * d.Q);
+  s.dvalues = take(M * Dd); s.dhb = take(BQ * (Dd / 2)); s.dz = take(BQ * 4);
+  s.padY = take(BQ * up4((size_t)(d.C > d.ncp ? d.C : d.ncp)));
+  const size_t tsz = maxcols * up4(BQ) > Dd * up4(M) ? maxcols * up4(BQ) : Dd * up4(M);     // transposed [features, rows padded to 4]
+  (void)rows_max;
+  s.tY = take(tsz);
+  s.tX = take(tsz);
+  s.wT = take(maxcols * Dd + 64);
+  if (sc) *sc = s;
+  return off;
+}
+
+GemmEpi gepi(const float* bias, float* out, int ldc, int act = ACT_NONE, const float* resid = nullptr, int ldr = 0) {
+  GemmEpi e; memset(&e, 0, sizeof e);
+  e.bias = bias; e.out_f32 = out; e.ldc = ldc; e.act = act; e.resid = resid; e.ldr = ldr;
+  return e;
+}
+// Y[M,N] = act(X[M,K] W[N,K]^T + b)
+int lin_fwd(const float* X, int ldx, const float* W, const float* b, int M, int N, int K, float* Y, int ldy, int act, hipStream_t s) {
+  return launch_gemm_f32(X, ldx, W, K, M, N, K, gepi(b, Y, ldy, act), s);
+}
+// dX[M,K] (+)= dY[M,N] W[N,K]       (N, ldy arbitrary: padded copies)
+int lin_bwd_x(const float* dY, int ldy, const float* W, int M, int N, int K, float* dX, bool accumulate, const Scratch& sc, hipStream_t s) {
+  const int Np = (int)up4(N);
+  const float* A = dY; int lda = ldy;
+  if (N != Np || ldy % 4) {
+    if (launch_copy2d(dY, ldy, sc.padY, Np, M, N, Np, s)) return 3;
+    A = sc.padY; lda = Np;
+  }
+  if (transpose_pad(W, K, N, K, sc.wT, Np, s)) return 3;              // wT [K, Np] = W^T, pad columns zero
+  return launch_gemm_f32(A, lda, sc.wT, Np, M, K, Np, gepi(nullptr, dX, K, ACT_NONE, accumulate ? dX : nullptr, K), s);
+}
+// dW[N,K] += dY[M,N]^T X[M,K];  db[N] += colsum(dY)
+int lin_bwd_w(const float* dY, int ldy, const float* X, int ldx, int M, int N, int K, float* dW, float* db, const Scratch& sc, hipStream_t s) {
+  const int Mp = (int)up4(M);
+  if (transpose_pad(dY, ldy, M, N, sc.tY, Mp, s)) return 3;           // [N, Mp]
+  if (transpose_pad(X, ldx, M, K, sc.tX, Mp, s)) return 3;            // [K, Mp]
+  int r = launch_gemm_f32(sc.tY, Mp, sc.tX, Mp, N, K, Mp, gepi(nullptr, dW, K, ACT_NONE, dW, K), s);
+  if (r) return r;
+  return db ? colsum_add(dY, ldy, M, N, db, s) : 0;
+}
+
+int build_cat(const Dims& d, const dod_dec_train_params* p, const Scratch& sc, hipStream_t s) {
+  const int Dd = d.Dd, HP = d.Hd * d.P;
+  TH(hipMemsetAsync(sc.cat_w, 0, (size_t)d.ncp * Dd * 4, s));
+  TH(hipMemsetAsync(sc.cat_b, 0, (size_t)d.ncp * 4, s));
+  TH(hipMemcpyAsync(sc.cat_w, p->refp_w, (size_t)2 * Dd * 4, hipMemcpyDeviceToDevice, s));
+  TH(hipMemcpyAsync(sc.cat_w + (size_t)2 * Dd, p->off_w, (size_t)HP * 2 * Dd * 4, hipMemcpyDeviceToDevice, s));
+  TH(hipMemcpyAsync(sc.cat_w + (size_t)(2 + HP * 2) * Dd, p->aw_w, (size_t)HP * Dd * 4, hipMemcpyDeviceToDevice, s));
+  TH(hipMemcpyAsync(sc.cat_b, p->refp_b, 2 * 4, hipMemcpyDeviceToDevice, s));
+  TH(hipMemcpyAsync(sc.cat_b + 2, p->off_b, (size_t)HP * 2 * 4, hipMemcpyDeviceToDevice, s));
+  TH(hipMemcpyAsync(sc.cat_b + 2 + HP * 2, p->aw_b, (size_t)HP * 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dod_decoder_train_last_error(void) { return g_terr.c_str(); }
+
+size_t dod_decoder_train_tape_bytes(const dod_config* cfg, int B, int N) {
+  Dims d; if (!make_dims(cfg, B, N, &d)) return 0;
+  return carve_tape(d, nullptr, nullptr) + 256;
+}
+size_t dod_decoder_train_workspace_bytes(const dod_config* cfg, int B, int N) {
+  Dims d; if (!make_dims(cfg, B, N, &d)) return 0;
+  return carve_scratch(d, nullptr, nullptr) + 256;
+}
+
+int dod_decoder_train_forward(const dod_config* cfg, const dod_dec_train_params* p, const float* memory, int B, int N, float dropout_p,
+                              uint64_t seed, float* det, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
+  Dims d;
+  if (!make_dims(cfg, B, N, &d)) return tfail(DOD_ERR_INVALID, "decoder train: unsupported configuration (deformable branch, head_dim <= 128, Dd <= 1024, Q <= %d)", MHA_MAXQ);
+  if (!p || !memory || !det || !tape || !ws) return tfail(DOD_ERR_INVALID, "decoder train: null buffer");
+  if (dropout_p < 0.f || dropout_p >= 1.f) return tfail(DOD_ERR_INVALID, "decoder train: dropout %g outside [0, 1)", dropout_p);
+  if (tape_bytes < dod_decoder_train_tape_bytes(cfg, B, N) || ws_bytes < dod_decoder_train_workspace_bytes(cfg, B, N))
+    return tfail(DOD_ERR_STATE, "decoder train: tape / workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  Tape t; Scratch sc;
+  carve_tape(d, (void*)(((uintptr_t)tape + 255) & ~(uintptr_t)255), &t);
+  carve_scratch(d, (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &sc);
+  const int BQ = d.BQ, Dd = d.Dd, Q = d.Q;
+  const float scale = 1.0f / sqrtf((float)d.dh);
+  int rc = build_cat(d, p, sc, s); if (rc) return rc;
+  TK(lin_fwd(memory, Dd, p->vp_w, p->vp_b, d.M, Dd, Dd, t.values, Dd, ACT_NONE, s));                     // tied layers: once
+  TK(launch_bcast_rows(p->query_embed, t.l[0].tgt_in, B, Q, Dd, s));
+  for (int j = 0; j < d.L; ++j) {
+    auto& L = t.l[j];
+    TK(lin_fwd(L.tgt_in, Dd, p->in_proj_w, p->in_proj_b, BQ, 3 * Dd, Dd, L.qkv, 3 * Dd, ACT_NONE, s));
+    hipLaunchKernelGGL(mha_fwd_train_kernel, dim3((unsigned)(((long)B * d.Hd * Q + 3) / 4)), dim3(256), 0, s, L.qkv, 3 * Dd, L.att, Dd, B, Q, d.Hd,
+                       Dd, d.dh, scale, dropout_p, site_key(seed, j, 0));
+    TH(hipGetLastError());
+    TK(lin_fwd(L.att, Dd, p->out_proj_w, p->out_proj_b, BQ, Dd, Dd, sc.y, Dd, ACT_NONE, s));
+    TK(dropout_add(L.tgt_in, sc.y, L.t1, (size_t)BQ * Dd, dropout_p, site_key(seed, j, 1), s));
+    TK(launch_layernorm(L.t1, nullptr, p->norm1_w, p->norm1_b, cfg->dec_ln_eps, BQ, Dd, L.tgt1, nullptr, s));
+    TH(hipMemsetAsync(L.proj, 0, (size_t)BQ * d.ncp * 4, s));
+    TK(launch_gemm_f32(L.tgt1, Dd, sc.cat_w, Dd, BQ, d.ncat, Dd, gepi(sc.cat_b, L.proj, d.ncp), s));
+    TK(launch_deform_sample(L.proj, d.ncp, t.values, B, Q, N, d.Hd, d.P, d.dh, d.fh, d.fw, L.samp, s, 0));
+    TK(lin_fwd(L.samp, Dd, p->op_w, p->op_b, BQ, Dd, Dd, sc.y, Dd, ACT_NONE, s));
+    TK(dropout_add(L.tgt1, sc.y, L.t2, (size_t)BQ * Dd, dropout_p, site_key(seed, j, 2), s));
+    TK(launch_layernorm(L.t2, nullptr, p->norm2_w, p->norm2_b, cfg->dec_ln_eps, BQ, Dd, L.tgt2, nullptr, s));
+    TK(lin_fwd(L.tgt2, Dd, p->lin1_w, p->lin1_b, BQ, d.F, Dd, L.hid, d.F, ACT_RELU, s));                   // taped: post-ReLU, pre-dropout
+    const float* hin = L.hid;
+    if (dropout_p > 0.f) { TK(dropout_add(nullptr, L.hid, sc.y, (size_t)BQ * d.F, dropout_p, site_key(seed, j, 3), s)); hin = sc.y; }
+    float* y2 = sc.dbig;                                                                                  // free during the forward
+    TK(lin_fwd(hin, d.F, p->lin2_w, p->lin2_b, BQ, Dd, d.F, y2, Dd, ACT_NONE, s));
+    TK(dropout_add(L.tgt2, y2, L.t3, (size_t)BQ * Dd, dropout_p, site_key(seed, j, 4), s));
+    float* nxt = j + 1 < d.L ? t.l[j + 1].tgt_in : t.hs;
+    TK(launch_layernorm(L.t3, nullptr, p->norm3_w, p->norm3_b, cfg->dec_ln_eps, BQ, Dd, nxt, nullptr, s));
+  }
+  const int C = d.C;
+  TK(launch_gemm_f32(t.hs, Dd, p->class_w, Dd, BQ, C, Dd, gepi(p->class_b, det, C + 4), s));
+  TK(lin_fwd(t.hs, Dd, p->bb0_w, p->bb0_b, BQ, Dd / 2, Dd, t.hb, Dd / 2, ACT_RELU, s));
+  TK(launch_gemm_f32(t.hb, Dd / 2, p->bb2_w, Dd / 2, BQ, 4, Dd / 2, gepi(p->bb2_b, det + C, C + 4, ACT_SIGMOID), s));
+  TK(launch_copy2d(det + C, C + 4, t.boxes, 4, BQ, 4, 4, s));
+  return DOD_OK;
+}
+
+int dod_decoder_train_backward(const dod_config* cfg, const dod_dec_train_params* p, const float* memory, int B, int N, float dropout_p,
+                               uint64_t seed, const float* d_det, const void* tape, size_t tape_bytes, const dod_dec_train_params* grads,
+                               float* d_memory, void* ws, size_t ws_bytes, void* stream) {
+  Dims d;
+  if (!make_dims(cfg, B, N, &d)) return tfail(DOD_ERR_INVALID, "decoder train: unsupported configuration");
+  if (!p || !memory || !d_det || !tape || !grads || !ws) return tfail(DOD_ERR_INVALID, "decoder train: null buffer");
+  if (tape_bytes < dod_decoder_train_tape_bytes(cfg, B, N) || ws_bytes < dod_decoder_train_workspace_bytes(cfg, B, N))
+    return tfail(DOD_ERR_STATE, "decoder train: tape / workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  Tape t; Scratch sc;
+  carve_tape(d, (void*)(((uintptr_t)tape + 255) & ~(uintptr_t)255), &t);
+  carve_scratch(d, (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &sc);
+  // gradients are written through the const-qualified struct's pointers (same layout as the parameters, float accumulators)
+  auto G = [](const float* q) { return const_cast<float*>(q); };
+  const int BQ = d.BQ, Dd = d.Dd, Q = d.Q, C = d.C, F = d.F, HP = d.Hd * d.P;
+  const float scale = 1.0f / sqrtf((float)d.dh);
+  const size_t nBD = (size_t)BQ * Dd;
+  int rc = build_cat(d, p, sc, s); if (rc) return rc;
+  TH(hipMemsetAsync(sc.dcat_w, 0, (size_t)d.ncp * Dd * 4, s));
+  TH(hipMemsetAsync(sc.dcat_b, 0, (size_t)d.ncp * 4, s));
+  TH(hipMemsetAsync(sc.dvalues, 0, (size_t)d.M * Dd * 4, s));
+  // ---- heads (detr_decoder.py:80-81; utils.py:14-30)
+  hipLaunchKernelGGL(sigmoid_bwd4_kernel, dim3((BQ * 4 + 255) / 256), dim3(256), 0, s, d_det + C, C + 4, t.boxes, 4, sc.dz, BQ);
+  TH(hipGetLastError());
+  TK(lin_bwd_w(sc.dz, 4, t.hb, Dd / 2, BQ, 4, Dd / 2, G(grads->bb2_w), G(grads->bb2_b), sc, s));
+  TK(lin_bwd_x(sc.dz, 4, p->bb2_w, BQ, 4, Dd / 2, sc.dhb, false, sc, s));
+  {
+    const size_t n = (size_t)BQ * (Dd / 2);
+    hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, sc.dhb, t.hb, sc.dhb, n, 0.f, 0ull);
+    TH(hipGetLastError());
+  }
+  TK(lin_bwd_w(sc.dhb, Dd / 2, t.hs, Dd, BQ, Dd / 2, Dd, G(grads->bb0_w), G(grads->bb0_b), sc, s));
+  TK(lin_bwd_x(sc.dhb, Dd / 2, p->bb0_w, BQ, Dd / 2, Dd, sc.dtgt, false, sc, s));
+  TK(lin_bwd_w(d_det, C + 4, t.hs, Dd, BQ, C, Dd, G(grads->class_w), G(grads->class_b), sc, s));
+  TK(lin_bwd_x(d_det, C + 4, p->class_w, BQ, C, Dd, sc.dtgt, true, sc, s));
+  // ---- layers, last to first (weights tied: every layer adds into the same gradient tensors)
+  for (int j = d.L - 1; j >= 0; --j) {
+    const auto& L = t.l[j];
+    // LN3 <- tgt2 + dropout4(linear2(dropout3(relu(linear1(tgt2)))))
+    TK(ln_bwd(L.t3, p->norm3_w, sc.dtgt, cfg->dec_ln_eps, BQ, Dd, sc.dt, G(grads->norm3_w), G(grads->norm3_b), s));
+    TK(dropout_add(nullptr, sc.dt, sc.dbr, nBD, dropout_p, site_key(seed, j, 4), s));                       // d(linear2 output)
+    const float* hin = L.hid;
+    if (dropout_p > 0.f) { TK(dropout_add(nullptr, L.hid, sc.y, (size_t)BQ * F, dropout_p, site_key(seed, j, 3), s)); hin = sc.y; }
+    TK(lin_bwd_w(sc.dbr, Dd, hin, F, BQ, Dd, F, G(grads->lin2_w), G(grads->lin2_b), sc, s));
+    TK(lin_bwd_x(sc.dbr, Dd, p->lin2_w, BQ, Dd, F, sc.dbig, false, sc, s));
+    {
+      const size_t n = (size_t)BQ * F;
+      hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, sc.dbig, L.hid, sc.dbig, n,
+                         dropout_p, site_key(seed, j, 3));
+      TH(hipGetLastError());
+    }
+    TK(lin_bwd_w(sc.dbig, F, L.tgt2, Dd, BQ, F, Dd, G(grads->lin1_w), G(grads->lin1_b), sc, s));
+    TK(lin_bwd_x(sc.dbig, F, p->lin1_w, BQ, F, Dd, sc.dt, true, sc, s));                                   // dt = d(tgt2): residual + FFN input
+    // LN2 <- tgt1 + dropout2(output_proj(samp))
+    TK(ln_bwd(L.t2, p->norm2_w, sc.dt, cfg->dec_ln_eps, BQ, Dd, sc.dtgt, G(grads->norm2_w), G(grads->norm2_b), s));   // dtgt = d(t2)
+    TK(dropout_add(nullptr, sc.dtgt, sc.dbr, nBD, dropout_p, site_key(seed, j, 2), s));
+    TK(lin_bwd_w(sc.dbr, Dd, L.samp, Dd, BQ, Dd, Dd, G(grads->op_w), G(grads->op_b), sc, s));
+    TK(lin_bwd_x(sc.dbr, Dd, p->op_w, BQ, Dd, Dd, sc.dt, false, sc, s));                                   // dt = d(samp)
+    TH(hipMemsetAsync(sc.dproj, 0, (size_t)BQ * d.ncp * 4, s));
+    hipLaunchKernelGGL(deform_bwd_kernel, dim3((unsigned)(((long)BQ * d.Hd + 3) / 4)), dim3(256), 0, s, L.proj, d.ncp, t.values, sc.dt, B, Q, N, d.Hd, d.P,
+                       d.dh, d.fh, d.fw, sc.dproj, sc.dvalues);
+    TH(hipGetLastError());
+    TK(lin_bwd_w(sc.dproj, d.ncp, L.tgt1, Dd, BQ, d.ncat, Dd, sc.dcat_w, sc.dcat_b, sc, s));
+    TK(lin_bwd_x(sc.dproj, d.ncp, sc.cat_w, BQ, d.ncat, Dd, sc.dtgt, true, sc, s));                        // dtgt = d(tgt1)
+    // LN1 <- tgt_in + dropout1(out_proj(att))
+    TK(ln_bwd(L.t1, p->norm1_w, sc.dtgt, cfg->dec_ln_eps, BQ, Dd, sc.dt, G(grads->norm1_w), G(grads->norm1_b), s));   // dt = d(t1)
+    TK(dropout_add(nullptr, sc.dt, sc.dbr, nBD, dropout_p, site_key(seed, j, 1), s));
+    TK(lin_bwd_w(sc.dbr, Dd, L.att, Dd, BQ, Dd, Dd, G(grads->out_proj_w), G(grads->out_proj_b), sc, s));
+    TK(lin_bwd_x(sc.dbr, Dd, p->out_proj_w, BQ, Dd, Dd, sc.dtgt, false, sc, s));                           // dtgt = d(att)
+    const unsigned nb = (unsigned)(((long)B * d.Hd * Q + 3) / 4);
+    hipLaunchKernelGGL(mha_bwd_row_kernel, dim3(nb), dim3(256), 0, s, L.qkv, 3 * Dd, sc.dtgt, Dd, sc.dqkv, sc.dS, sc.Pd, B, Q, d.Hd, Dd, d.dh, scale,
+                       dropout_p, site_key(seed, j, 0));
+    TH(hipGetLastError());
+    hipLaunchKernelGGL(mha_bwd_col_kernel, dim3(nb), dim3(256), 0, s, L.qkv, 3 * Dd, sc.dtgt, Dd, sc.dqkv, sc.dS, sc.Pd, B, Q, d.Hd, Dd, d.dh, scale);
+    TH(hipGetLastError());
+    TK(lin_bwd_w(sc.dqkv, 3 * Dd, L.tgt_in, Dd, BQ, 3 * Dd, Dd, G(grads->in_proj_w), G(grads->in_proj_b), sc, s));
+    TK(lin_bwd_x(sc.dqkv, 3 * Dd, p->in_proj_w, BQ, 3 * Dd, Dd, sc.dt, true, sc, s));                      // dt = d(tgt_in): next (earlier) layer's d(output)
+    TH(hipMemcpyAsync(sc.dtgt, sc.dt, nBD * 4, hipMemcpyDeviceToDevice, s));
+  }
+  // query embedding: tgt_0[b] = query_embed for every image (detr_decoder.py:59)
+  hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)(((size_t)Q * Dd + 255) / 256)), dim3(256), 0, s, sc.dtgt, G(grads->query_embed), B, (size_t)Q * Dd);
+  TH(hipGetLastError());
+  // fused small linear -> its three parameters
+  {
+    float* dw = sc.dcat_w; float* dbv = sc.dcat_b;
+    TK(add_inplace(G(grads->refp_w), dw, (size_t)2 * Dd, s));
+    TK(add_inplace(G(grads->off_w), dw + (size_t)2 * Dd, (size_t)HP * 2 * Dd, s));
+    TK(add_inplace(G(grads->aw_w), dw + (size_t)(2 + HP * 2) * Dd, (size_t)HP * Dd, s));
+    TK(add_inplace(G(grads->refp_b), dbv, 2, s));
+    TK(add_inplace(G(grads->off_b), dbv + 2, (size_t)HP * 2, s));
+    TK(add_inplace(G(grads->aw_b), dbv + 2 + HP * 2, (size_t)HP, s));
+  }
+  // value projection (computed once for the tied layers: d(values) is the sum over layers)
+  TK(lin_bwd_w(sc.dvalues, Dd, memory, Dd, d.M, Dd, Dd, G(grads->vp_w), G(grads->vp_b), sc, s));
+  if (d_memory) TK(lin_bwd_x(sc.dvalues, Dd, p->vp_w, d.M, Dd, Dd, d_memory, false, sc, s));
+  return DOD_OK;
+}
+
+}  // extern "C"

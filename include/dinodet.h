@@ -220,6 +220,38 @@ int dod_match_cost(const float* det, int B, int Q, int C, const int64_t* labels,
                    const int32_t* gt_offsets, int G, float w_class, float w_bbox, float w_giou, float alpha, float gamma,
                    int rows_from, float* cost, void* stream);
 
+/* ---- native training step of the decoder + heads (first slice) ---------------------------------------
+ * What `loss.backward()` at dino_detector/train.py:1101 needs from DETRDecoder.forward (detr_decoder.py:47-83) over the
+ * weight-tied DeformableDecoderLayer (deformable_attention.py:215-268, tied at :284): a train-mode forward (dropout at the
+ * reference's five sites, masks from a counter-based hash of `seed`) that tapes its activations, and the backward producing
+ * the gradients of every decoder / head parameter and of `memory` (which the caller feeds on into the projection and the
+ * LoRA-adapted blocks).  Stateless: the shapes come from `cfg`, the fp32 parameters from the caller's own tensors.
+ * All pointers are device pointers.  `grads` has the layout of the parameters; its tensors are float ACCUMULATORS (the layers
+ * share one set of weights; zero them for a plain gradient).  The same `dropout_p` / `seed` must be given to both calls. */
+typedef struct dod_dec_train_params {
+  const float *query_embed;                      /* [Q, Dd]            detr_decoder.py:15 */
+  const float *class_w, *class_b;                /* [C, Dd], [C]       :40 */
+  const float *bb0_w, *bb0_b, *bb2_w, *bb2_b;    /* bbox_embed.mlp.{0,2}  :39-41 */
+  const float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;          /* self_attn (nn.MultiheadAttention) */
+  const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b;
+  const float *lin1_w, *lin1_b, *lin2_w, *lin2_b;
+  const float *refp_w, *refp_b;                  /* reference_points_proj [2, Dd] */
+  const float *off_w, *off_b, *aw_w, *aw_b;      /* cross_attn.sampling_offsets / attention_weights */
+  const float *vp_w, *vp_b, *op_w, *op_b;        /* cross_attn.value_proj / output_proj */
+} dod_dec_train_params;
+size_t dod_decoder_train_tape_bytes(const dod_config* cfg, int B, int N);
+size_t dod_decoder_train_workspace_bytes(const dod_config* cfg, int B, int N);
+/* memory [B, N, Dd] -> detections [B, Q, C+4] (as dod_decoder_forward), activations into `tape` (keep it until the backward) */
+int dod_decoder_train_forward(const dod_config* cfg, const dod_dec_train_params* params, const float* memory, int B, int N,
+                              float dropout_p, uint64_t seed, float* detections, void* tape, size_t tape_bytes,
+                              void* workspace, size_t workspace_bytes, void* stream);
+/* d_detections [B, Q, C+4] -> grads (accumulated) and d_memory [B, N, Dd] (overwritten; may be NULL) */
+int dod_decoder_train_backward(const dod_config* cfg, const dod_dec_train_params* params, const float* memory, int B, int N,
+                               float dropout_p, uint64_t seed, const float* d_detections, const void* tape, size_t tape_bytes,
+                               const dod_dec_train_params* grads, float* d_memory, void* workspace, size_t workspace_bytes,
+                               void* stream);
+const char* dod_decoder_train_last_error(void);
+
 /* Tuning aid: when dev_buf is non-NULL the large bf16 GEMM kernel stores 4 x uint64 per workgroup
  * {realtime at start, after the K loop, at exit, blockIdx} (100 MHz s_memrealtime); NULL switches it off.
  * Used by tools/gemm_timeline.py. */

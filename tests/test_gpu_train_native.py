@@ -1,0 +1,145 @@
+"""`-m gpu`: the native training step of the decoder + heads (dec_train.hip through dod_decoder_train_forward / _backward) against
+the autograd composite of the same math (models/_autograd.py, itself pinned to the reference goldens by
+tests/test_train_composite.py): forward identical, every parameter gradient and d(memory) within 1e-4 -- the gradients
+`loss.backward()` at train.py:1101 produces for the decoder and heads."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dinov2_od_amd import synth
+from tests import cases
+from tests.cases import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _decoder(dc, dropout=0.0):
+    from dinov2_od_amd.models import DETRDecoder
+    from tests import gpu_util as G
+    m = DETRDecoder(dc.num_queries, dc.hidden_dim, dc.nheads, dc.num_layers, dc.num_classes, dim_feedforward=dc.dim_feedforward,
+                    dropout=dropout, n_points=dc.n_points, use_deformable=True, precision="fp32")
+    G.load_np_state(m, synth.decoder_state_dict(dc, seed=1, prefix=""))
+    m = m.to(G.dev()).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = dropout
+    return m
+
+
+def _loss(o, wl, wb):
+    return (o["pred_logits"] * wl).sum() + (o["pred_boxes"] * wb).sum()
+
+
+def _run(m, mem, wl, wb, native):
+    os.environ["DINODET_NATIVE_TRAIN"] = "1" if native else "0"
+    try:
+        m.zero_grad(set_to_none=True)
+        x = mem.clone().requires_grad_(True)
+        o = m(x)
+        _loss(o, wl, wb).backward()
+        g = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        return o["pred_logits"].detach().clone(), o["pred_boxes"].detach().clone(), x.grad.detach().clone(), g
+    finally:
+        os.environ.pop("DINODET_NATIVE_TRAIN", None)
+
+
+CASES = [  # Dd, Hd, Q, layers, F, C, P, B, N
+    (128, 4, 7, 2, 256, 11, 2, 2, 26),       # micro: (h, w) = (2, 13)
+    (128, 4, 7, 2, 256, 11, 2, 3, 257),      # prime token count: (1, 257)
+    (192, 2, 5, 2, 256, 11, 4, 2, 1370),     # head_dim 96, 4 points, (10, 137)
+    (256, 4, 25, 2, 512, 91, 2, 2, 257),     # the --lightweight decoder (train.py:607-640)
+    (768, 8, 100, 3, 1024, 91, 2, 2, 257),   # config.py:21-35 defaults (tied x3), 224x224 memory
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"Dd{c[0]}_Q{c[2]}_N{c[8]}" for c in CASES])
+def test_native_decoder_backward_matches_composite_autograd(case):
+    from tests import gpu_util as G
+    Dd, Hd, Q, layers, F, C, P, B, N = case
+    dc = cases.dec_cfg(True, Dd, Hd, Q, layers, F, C, P)
+    m = _decoder(dc)
+    mem = G.to_gpu(synth.normal(3, f"memory.train.{N}.{Dd}", (B, N, Dd), 1.0))
+    wl = G.to_gpu(synth.normal(5, "train.wl", (B, Q, C), 1.0))
+    wb = G.to_gpu(synth.normal(5, "train.wb", (B, Q, 4), 1.0))
+    l0, b0, dx0, g0 = _run(m, mem, wl, wb, native=False)
+    l1, b1, dx1, g1 = _run(m, mem, wl, wb, native=True)
+    assert rel_err(l1.cpu().numpy(), l0.cpu().numpy()) < 1e-5 and rel_err(b1.cpu().numpy(), b0.cpu().numpy()) < 1e-5
+    assert set(g0) == set(g1) and len(g1) >= 30
+    worst = ("", 0.0)
+    for k in g0:
+        e = rel_err(g1[k].cpu().numpy(), g0[k].cpu().numpy())
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 1e-4, (k, e)
+    e = rel_err(dx1.cpu().numpy(), dx0.cpu().numpy())
+    print(f"native vs composite gradients {case}: worst parameter {worst[0]} {worst[1]:.2e}, d(memory) {e:.2e}")
+    assert e < 1e-4
+    # the unused reference_points head (detr_decoder.py:44-45) gets no gradient in either path
+    assert not any(k.startswith("reference_points.") for k in g1)
+
+
+def test_native_decoder_dropout_masks_are_consistent_and_seeded():
+    """dropout 0.1 at the reference's five sites: the forward is a deterministic function of the seed, the drop rate is right, and
+    the backward applies the SAME masks (directional finite difference of the loss against the analytic gradient)."""
+    from dinov2_od_amd.models import _native_train as nt
+    from tests import gpu_util as G
+    dc = cases.dec_cfg(True, 128, 4, 16, 2, 256, 11, 2)
+    m = _decoder(dc, dropout=0.1)
+    B, N = 4, 257
+    mem = G.to_gpu(synth.normal(3, "memory.drop", (B, N, 128), 1.0))
+    a = nt.decoder_train(m, mem, seed=1234).detach().clone()
+    b = nt.decoder_train(m, mem, seed=1234).detach().clone()
+    c = nt.decoder_train(m, mem, seed=99).detach().clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    m.eval()                                             # p = 0 through the same entry
+    d = nt.decoder_train(m, mem, seed=1234).detach().clone()
+    m.train()
+    assert not torch.allclose(a, d)
+    # finite-difference check along a random direction of linear1.weight and of the memory
+    w = m.decoder.layers[0].linear1.weight
+    vw = torch.randn_like(w) * 1e-3
+    vx = torch.randn_like(mem) * 1e-3
+    wl = G.to_gpu(synth.normal(5, "drop.wl", (B, 16, 15), 1.0))
+
+    def f(x):
+        return (nt.decoder_train(m, x, seed=77) * wl).sum()
+    x = mem.clone().requires_grad_(True)
+    m.zero_grad(set_to_none=True)
+    f(x).backward()
+    ana = float((w.grad * vw).sum() + (x.grad * vx).sum())
+    with torch.no_grad():
+        w.add_(vw); lp = float(f(mem + vx)); w.sub_(2 * vw); lm = float(f(mem - vx)); w.add_(vw)
+    num = (lp - lm) / 2
+    print(f"dropout directional derivative: analytic {ana:.5f}, central difference {num:.5f}")
+    assert abs(ana - num) < 2e-2 * max(1.0, abs(num)) + 2e-3
+
+
+def test_detector_train_step_uses_the_native_decoder_backward():
+    """train.py:1079-1109 on the drop-in detector: the decoder / head gradients come from the native backward, d(memory) continues
+    through the composite's projection and LoRA blocks; same gradients as the all-composite step."""
+    from tests import gpu_util as G
+    bb, dc = cases.cfg1(25)
+    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-small")
+    m.train()
+    m._dropout_p = m.decoder._dropout_p = 0.0
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    x = G.to_gpu(synth.make_pixels(2, 224, 224, seed=0))
+
+    def run(native):
+        os.environ["DINODET_NATIVE_TRAIN"] = "1" if native else "0"
+        try:
+            m.zero_grad(set_to_none=True)
+            o = m(x)
+            (o["pred_logits"].square().mean() + o["pred_boxes"].mean()).backward()
+            return o["pred_logits"].detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        finally:
+            os.environ.pop("DINODET_NATIVE_TRAIN", None)
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert rel_err(l1.cpu().numpy(), l0.cpu().numpy()) < 1e-4
+    assert set(g0) == set(g1) and any("lora_A" in k for k in g1) and any(k.startswith("backbone.projection") for k in g1)
+    for k in g0:
+        assert rel_err(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-3, k      # LoRA grads pass through two blocks of fp32 autograd
