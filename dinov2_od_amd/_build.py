@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdinodet.so")
 OBJ = os.path.join(ROOT, "build", "obj")
 SOURCES = ["dod_api.hip", "gemm_bf16.hip", "gemm_f32.hip", "attn_bf16.hip", "attn_f32.hip", "rowops.hip", "deform.hip",
-           "postproc.hip", "matchcost.hip", "gemm_fp8.hip", "attn_x3.hip", "gemm_x3.hip", "preproc.hip", "attn_f32m.hip", "gemm_pp.hip", "dec_train.hip"]
+           "postproc.hip", "matchcost.hip", "gemm_fp8.hip", "attn_x3.hip", "gemm_x3.hip", "preproc.hip", "attn_f32m.hip", "gemm_pp.hip", "dec_train.hip", "patch_embed.hip"]
 HEADERS = [os.path.join(CSRC, "dod_common.h"), os.path.join(CSRC, "gemm_epi.h"), os.path.join(ROOT, "include", "dinodet.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include")]

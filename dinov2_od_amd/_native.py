@@ -56,6 +56,7 @@ SYMBOLS = {
     "dod_workspace_bytes": (_SZ, [_P, _I, _I, _I]),
     "dod_num_tokens": (_I, [_P, _I, _I]),
     "dod_forward": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
+    "dod_forward_u8": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "dod_backbone_forward": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "dod_backbone_prefix": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     "dod_decoder_forward": (_I, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
@@ -78,6 +79,7 @@ SYMBOLS = {
     "dod_postprocess_workspace_bytes": (_SZ, [_I, _I, _I]),
     "dod_postprocess": (_I, [_P, _I, _I, _I, _P, _F, _P, C.c_int64, _P, _P, _SZ, _P]),
     "dod_preprocess": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "dod_preprocess_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "dod_match_cost": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P, _P]),
     "dod_decoder_train_tape_bytes": (_SZ, [C.POINTER(DodConfig), _I, _I]),
     "dod_decoder_train_workspace_bytes": (_SZ, [C.POINTER(DodConfig), _I, _I]),

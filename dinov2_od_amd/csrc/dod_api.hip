@@ -55,6 +55,7 @@ struct dod_handle {
   std::vector<BLayer> L;
   void* Wpatch = nullptr; int Kp = 0;
   bf16_t* Wpatch2 = nullptr; int Kp2 = 0;   // bf16x3 mode: pair-layout patch weight, K padded to a multiple of 32
+  bf16_t* Wpe = nullptr;                    // fused patch embed (patch_embed.hip): weight in the kernel's k order (pair layout in bf16x3 mode)
   float *bpatch = nullptr, *cls = nullptr, *pos = nullptr, *lnfw = nullptr, *lnfb = nullptr, *bproj = nullptr;
   void* Wproj = nullptr;
   std::vector<DLayer> DL;
@@ -260,6 +261,11 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
     const int K = 3 * p * p;
     h->Kp = is_bf16(h) ? (K + 63) / 64 * 64 : K;
     if (W) h->Wpatch = P.pack_operand(W->ptr, D, K, h->Kp);
+    h->Wpe = nullptr;
+    if (W && (is_bf16(h) || is_x3(h)) && p >= 2 && p <= 16 && p % 2 == 0 && D % 4 == 0 && !getenv("DINODET_NO_FUSED_PATCH")) {
+      bf16_t* wp = P.alloc<bf16_t>((size_t)D * 3 * (p / 2) * 32 * (is_x3(h) ? 2 : 1));
+      if (wp && !launch_patch_pack(W->ptr, D, p, wp, is_x3(h) ? 1 : 0, s)) h->Wpe = wp;
+    }
     if (W && is_x3(h)) {
       h->Kp2 = (K + 31) / 32 * 32;
       float* padded = P.alloc<float>((size_t)D * h->Kp2, true);
@@ -501,7 +507,7 @@ GemmEpi epi(const float* bias, float* of32, void* obf, int ldc, int act = ACT_NO
 // DINOv2Backbone.forward (dinov2_backbone.py:58-67) -> ws.mem (operand dtype) and/or feat_f32
 // stop_blocks >= 0: run the embeddings and the first stop_blocks encoder blocks only and copy the fp32 residual stream to x_out
 int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const BbWS& ws, float* feat_f32, bool want_mem, hipStream_t s,
-                  int stop_blocks = -1, float* x_out = nullptr) {
+                  int stop_blocks = -1, float* x_out = nullptr, const unsigned char* pixels_u8 = nullptr) {
   const dod_config& g = h->cfg;
   const bool bf = is_bf16(h);
   const int D = g.hidden, F = g.ffn_hidden, p = g.patch;
@@ -509,8 +515,14 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   if (!h->has_bb) return fail(h, DOD_ERR_STATE, "no backbone weights were registered");
   if (bf && D / g.heads != 64) return fail(h, DOD_ERR_INVALID, "bf16 attention kernel needs head_dim 64 (got %d)", D / g.heads);
   int rc = prepare_impl(h, H, W, s); if (rc) return rc;
-  // K1 + K2: im2col -> GEMM with bias + position add, rows remapped past the CLS slot
-  if (is_x3(h) && h->Wpatch2 && (size_t)3 * D * 6 >= (size_t)h->Kp2 * 4) {   // split-product patch embed (pair operand staged in ws.qkv)
+  // K1 + K2.  Fused form (patch_embed.hip): implicit im2col in the GEMM's load stage, bias + position add in its epilogue; the
+  // uint8 HWC input of the device input pipeline (dod_forward_u8) exists only there.
+  if (pixels_u8 && !h->Wpe) return fail(h, DOD_ERR_INVALID, "uint8 input needs the fused patch embed (bf16 / bf16x3 / fp8 precision, even patch size <= 16)");
+  if (h->Wpe) {
+    ProfScope ps(h, s, PC_GEMM_BF16, 2.0 * B * Np * (double)D * 3.0 * p * p);
+    KCHK(h, launch_patch_embed(pixels_u8 ? (const void*)pixels_u8 : (const void*)pixels, pixels_u8 ? 1 : 0, B, H, W, p, h->Wpe, is_x3(h) ? 1 : 0,
+                               h->bpatch, h->pos_hw, ws.x, D, s));
+  } else if (is_x3(h) && h->Wpatch2 && (size_t)3 * D * 6 >= (size_t)h->Kp2 * 4) {   // split-product patch embed (pair operand staged in ws.qkv)
     const int K2 = h->Kp2;
     KCHK(h, launch_im2col(pixels, B, H, W, p, K2, (float*)ws.hbuf, nullptr, s));
     KCHK(h, launch_split2((const float*)ws.hbuf, K2, (bf16_t*)ws.qkv, B * Np, K2, s));
@@ -911,6 +923,20 @@ int dod_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* 
   }
   for (int i = 0; i < 2; ++i) HIPCHK(h, hipStreamWaitEvent(s, h->join_ev[i], 0));
   return DOD_OK;
+}
+
+int dod_forward_u8(dod_handle* h, const uint8_t* pixels_hwc, int B, int H, int W, float* det, void* workspace, size_t wsb, void* stream) {
+  int rc;
+  if (!check_common(h, B, H, W, &rc)) return rc;
+  if (!pixels_hwc || !det || !workspace) return fail(h, DOD_ERR_INVALID, "null buffer");
+  if (wsb < dod_workspace_bytes(h, B, H, W)) return fail(h, DOD_ERR_STATE, "workspace too small: %zu < %zu", wsb, dod_workspace_bytes(h, B, H, W));
+  const int N = dod_num_tokens(h, H, W);
+  Carver c(align_ws(workspace));
+  BbWS bw; DecWS dw;
+  carve_backbone(h, c, B, N, &bw);
+  carve_decoder(h, c, B, N, &dw, false);
+  rc = backbone_impl(h, nullptr, B, H, W, bw, nullptr, true, (hipStream_t)stream, -1, nullptr, pixels_hwc); if (rc) return rc;
+  return decoder_impl(h, bw.mem, B, N, dw, det, (hipStream_t)stream);
 }
 
 int dod_backbone_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* features, void* workspace, size_t wsb, void* stream) {

@@ -124,6 +124,11 @@ int launch_attn_f32(const AttnF32& a, hipStream_t s);
 
 // patch im2col: img [B,3,H,W] fp32 -> A [B*gh*gw, Kp] (k = c*p*p + i*p + j, zero padded to Kp)
 int launch_im2col(const float* img, int B, int H, int W, int patch, int Kp, float* out_f32, bf16_t* out_bf16, hipStream_t s);
+// fused patch embedding with implicit im2col (patch_embed.hip): W [D,3,p,p] -> kernel order (launch_patch_pack), then
+// img (fp32 CHW, or uint8 HWC with ToTensor's /255 applied in the load) -> x[b][1 + m][:] = conv + bias + pos[1 + m]
+int launch_patch_pack(const float* W, int D, int p, bf16_t* out, int x3, hipStream_t s);
+int launch_patch_embed(const void* img, int u8, int B, int H, int W, int p, const bf16_t* Wp, int x3, const float* bias, const float* pos,
+                       float* out, int D, hipStream_t s);
 // x[b][0][:] = cls + pos[0]
 int launch_cls_row(const float* cls, const float* pos, float* x, int B, int N, int D, hipStream_t s);
 // bicubic resize of the patch position table (torch upsample_bicubic2d, A=-0.75, align_corners=False)

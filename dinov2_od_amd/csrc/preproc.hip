@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void pp_horizontal_kernel(const unsigned char*
 __global__ __launch_bounds__(256) void pp_vertical_kernel(const unsigned char* __restrict__ tmp,
                                                           const long long* __restrict__ tmp_offs,
                                                           const int* __restrict__ hs, int out_h, int out_w,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, unsigned char* __restrict__ out_u8) {
   __shared__ int kk[PP_MAXK];
   __shared__ int s_lo, s_n;
   const int b = blockIdx.y, oy = blockIdx.x;
@@ -105,14 +105,15 @@ __global__ __launch_bounds__(256) void pp_vertical_kernel(const unsigned char* _
     int acc = 1 << (PP_BITS - 1);
     for (int y = 0; y < n; ++y) acc += (int)img[(size_t)(lo + y) * rowbytes + t] * kk[y];
     const int ox = t / 3, c = t - ox * 3;
-    out[(((size_t)b * 3 + c) * out_h + oy) * out_w + ox] = (float)pp_clip8(acc) / 255.0f;
+    if (out_u8) out_u8[((size_t)b * out_h + oy) * rowbytes + t] = pp_clip8(acc);      // resampled bytes, HWC: the fused patch embed divides by 255
+    else out[(((size_t)b * 3 + c) * out_h + oy) * out_w + ox] = (float)pp_clip8(acc) / 255.0f;
   }
 }
 
-extern "C" int dod_preprocess(const uint8_t* src, const int64_t* src_offs, const int32_t* heights, const int32_t* widths, int B,
-                              int max_h, int max_w, int out_h, int out_w, uint8_t* tmp, const int64_t* tmp_offs, float* out,
-                              void* stream) {
-  if (!src || !src_offs || !heights || !widths || !tmp || !tmp_offs || !out) return DOD_ERR_INVALID;
+static int preprocess_impl(const uint8_t* src, const int64_t* src_offs, const int32_t* heights, const int32_t* widths, int B,
+                           int max_h, int max_w, int out_h, int out_w, uint8_t* tmp, const int64_t* tmp_offs, float* out, uint8_t* out_u8,
+                           void* stream) {
+  if (!src || !src_offs || !heights || !widths || !tmp || !tmp_offs || (!out && !out_u8)) return DOD_ERR_INVALID;
   if (B <= 0 || out_h <= 0 || out_w <= 0 || max_h <= 0 || max_w <= 0 || B > 65535) return DOD_ERR_INVALID;
   // window taps ceil(max(scale, 1)) * 2 + 1 must fit PP_MAXK
   const int kh = ((max_w + out_w - 1) / out_w) * 2 + 1, kv = ((max_h + out_h - 1) / out_h) * 2 + 1;
@@ -122,6 +123,17 @@ extern "C" int dod_preprocess(const uint8_t* src, const int64_t* src_offs, const
                      (const unsigned char*)src, (const long long*)src_offs, heights, widths, out_w, (unsigned char*)tmp,
                      (const long long*)tmp_offs);
   hipLaunchKernelGGL(pp_vertical_kernel, dim3(out_h, B), dim3(256), 0, s, (const unsigned char*)tmp, (const long long*)tmp_offs,
-                     heights, out_h, out_w, out);
+                     heights, out_h, out_w, out, (unsigned char*)out_u8);
   return hipGetLastError() == hipSuccess ? DOD_OK : DOD_ERR_HIP;
+}
+
+extern "C" int dod_preprocess(const uint8_t* src, const int64_t* src_offs, const int32_t* heights, const int32_t* widths, int B,
+                              int max_h, int max_w, int out_h, int out_w, uint8_t* tmp, const int64_t* tmp_offs, float* out,
+                              void* stream) {
+  return preprocess_impl(src, src_offs, heights, widths, B, max_h, max_w, out_h, out_w, tmp, tmp_offs, out, nullptr, stream);
+}
+extern "C" int dod_preprocess_u8(const uint8_t* src, const int64_t* src_offs, const int32_t* heights, const int32_t* widths, int B,
+                                 int max_h, int max_w, int out_h, int out_w, uint8_t* tmp, const int64_t* tmp_offs, uint8_t* out_hwc,
+                                 void* stream) {
+  return preprocess_impl(src, src_offs, heights, widths, B, max_h, max_w, out_h, out_w, tmp, tmp_offs, nullptr, out_hwc, stream);
 }

@@ -164,6 +164,26 @@ class Engine:
                 return self._forward_graph(x)
             return self._launch_forward(x)
 
+    def forward_u8(self, pixels_hwc, named):
+        """uint8 [B, H, W, 3] (preprocess_batch(..., as_uint8=True)) -> packed detections; ToTensor's / 255 happens in the patch
+        embedding's load stage (dod_forward_u8)"""
+        x = pixels_hwc
+        if x.dim() != 4 or x.shape[-1] != 3 or x.dtype != torch.uint8:
+            raise ValueError(f"expected uint8 [batch, H, W, 3], got {x.dtype} {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("pixels must be on the GPU: the MI355X path has no CPU fallback")
+        x = x.contiguous()
+        self.sync_weights(named)
+        B, H, W, _ = x.shape
+        nbytes = self._lib.dod_workspace_bytes(self._h, B, H, W)
+        if nbytes == 0:
+            raise ValueError(f"unsupported input {tuple(x.shape)}")
+        with self._on_device(x):
+            ws = self._workspace(nbytes, x.device)
+            det = torch.empty(B, self.dc.num_queries, self.dc.num_classes + 4, dtype=torch.float32, device=x.device)
+            nat.check(self._lib.dod_forward_u8(self._h, nat.ptr(x), B, H, W, nat.ptr(det), nat.ptr(ws), ws.numel(), nat.stream_ptr()), self._h)
+        return det
+
     def backbone_forward(self, pixel_values, named):
         x = self._check_pixels(pixel_values)
         self.sync_weights(named)

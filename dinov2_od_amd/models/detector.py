@@ -60,6 +60,14 @@ class DINOv2ObjectDetector(_EngineMixin, nn.Module):   # state-dict keys already
             return torch.cat([o["pred_logits"], o["pred_boxes"]], dim=-1)
         return self._get_engine().forward(pixel_values, self._engine_named())
 
+    def forward_packed_u8(self, pixels_hwc):
+        """eval-mode forward straight from the device input pipeline's bytes: uint8 [B, H, W, 3] as
+        `preprocess_batch(images, size, as_uint8=True)` returns them (Resize done, ToTensor not yet: train.py:584-587) -> packed
+        detections.  Identical, bit for bit, to forward_packed(preprocess_batch(images, size)); bf16 / bf16x3 / fp8 precision."""
+        if self.training:
+            raise RuntimeError("forward_packed_u8 is an eval-mode entry (train() takes the fp32 batch)")
+        return self._get_engine().forward_u8(pixels_hwc, self._engine_named())
+
     def forward(self, pixel_values):
         """pixel_values [batch, 3, H, W] -> {"pred_logits", "pred_boxes"} (detector.py:58-69)."""
         if self._use_autograd(pixel_values):            # train(): autograd composite of the same math (detector.py:58-69)

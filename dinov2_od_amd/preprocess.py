@@ -25,9 +25,11 @@ def _staging(nbytes):
     return _STAGE
 
 
-def preprocess_batch(images, size=(224, 224), device="cuda"):
+def preprocess_batch(images, size=(224, 224), device="cuda", as_uint8=False):
     """images: sequence of uint8 RGB images [H_i, W_i, 3] (numpy arrays, torch tensors or PIL images); size: (height, width)
-    as torchvision's Resize takes it.  Returns float32 [B, 3, height, width] on `device`."""
+    as torchvision's Resize takes it.  Returns float32 [B, 3, height, width] on `device` -- or, with as_uint8, the resampled
+    bytes uint8 [B, height, width, 3] (before ToTensor) for `model.forward_packed_u8`, whose patch-embedding kernel divides by 255
+    in its load stage: the fp32 batch then never goes through HBM."""
     out_h, out_w = (int(size), int(size)) if np.isscalar(size) else (int(size[0]), int(size[1]))
     arrs = []
     for im in images:
@@ -57,6 +59,11 @@ def preprocess_batch(images, size=(224, 224), device="cuda"):
     _STAGE_BUSY.record()
     meta = [torch.from_numpy(x).to(dev) for x in (src_offs, hs, ws, tmp_offs)]
     tmp = torch.empty(int(tsz.sum()), dtype=torch.uint8, device=dev)
+    if as_uint8:
+        out = torch.empty(B, out_h, out_w, 3, dtype=torch.uint8, device=dev)
+        nat.check(nat.lib().dod_preprocess_u8(nat.ptr(src), nat.ptr(meta[0]), nat.ptr(meta[1]), nat.ptr(meta[2]), B, int(hs.max()), int(ws.max()),
+                                              out_h, out_w, nat.ptr(tmp), nat.ptr(meta[3]), nat.ptr(out), nat.stream_ptr()))
+        return out
     out = torch.empty(B, 3, out_h, out_w, dtype=torch.float32, device=dev)
     nat.check(nat.lib().dod_preprocess(nat.ptr(src), nat.ptr(meta[0]), nat.ptr(meta[1]), nat.ptr(meta[2]), B, int(hs.max()), int(ws.max()),
                                        out_h, out_w, nat.ptr(tmp), nat.ptr(meta[3]), nat.ptr(out), nat.stream_ptr()))
@@ -66,8 +73,8 @@ def preprocess_batch(images, size=(224, 224), device="cuda"):
 class ResizeToTensor:
     """Batch counterpart of `transforms.Compose([transforms.Resize(size), transforms.ToTensor()])` (train.py:584-587)."""
 
-    def __init__(self, size=(224, 224), device="cuda"):
-        self.size, self.device = size, device
+    def __init__(self, size=(224, 224), device="cuda", as_uint8=False):
+        self.size, self.device, self.as_uint8 = size, device, as_uint8
 
     def __call__(self, images):
-        return preprocess_batch(images, self.size, self.device)
+        return preprocess_batch(images, self.size, self.device, self.as_uint8)

@@ -109,6 +109,13 @@ int dod_num_tokens(const dod_handle* h, int H, int W);     /* N = (H/p)*(W/p) + 
 int dod_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* detections,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same forward from the device input pipeline's bytes: pixels_hwc = uint8 [B, H, W, 3] (dod_preprocess_u8: the resampled
+ * image before ToTensor); the patch-embedding kernel applies ToTensor's x / 255 in its load stage, so the fp32 CHW batch of
+ * train.py:584-587 never exists in HBM.  Same detections, bit for bit, as dod_forward on dod_preprocess's output.
+ * bf16 / bf16x3 / fp8 precision only (the fused patch embedding). */
+int dod_forward_u8(dod_handle* h, const uint8_t* pixels_hwc, int B, int H, int W, float* detections,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* DINOv2Backbone.forward: pixels -> features [B, N, out_dim] fp32 (CLS token at index 0). */
 int dod_backbone_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* features,
                          void* workspace, size_t workspace_bytes, void* stream);
@@ -208,6 +215,11 @@ int dod_postprocess(const float* det, int B, int Q, int C, const int64_t* image_
 int dod_preprocess(const uint8_t* src, const int64_t* src_offs, const int32_t* heights, const int32_t* widths, int B,
                    int max_h, int max_w, int out_h, int out_w, uint8_t* tmp, const int64_t* tmp_offs, float* out,
                    void* stream);
+
+/* as dod_preprocess, stopping before ToTensor: out_hwc = uint8 [B, out_h, out_w, 3], the input of dod_forward_u8 */
+int dod_preprocess_u8(const uint8_t* src, const int64_t* src_offs, const int32_t* heights, const int32_t* widths, int B,
+                      int max_h, int max_w, int out_h, int out_w, uint8_t* tmp, const int64_t* tmp_offs, uint8_t* out_hwc,
+                      void* stream);
 
 /* ---- Hungarian-matcher cost matrices on device -------------------------------------
  * Replaces the per-image cost computation of HungarianMatcher.forward, dino_detector/matching.py:79-98 (focal class

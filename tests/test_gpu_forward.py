@@ -563,3 +563,34 @@ def test_reference_point_conditioning_sweep(G, precision):
             floor = rel_err(f32[k].numpy(), exact[k].numpy())
             print(f"sigma {sigma} {precision} {k}: HIP vs fp64 {got:.2e}, fp32 CPU vs fp64 {floor:.2e}")
             assert got < max(TOL if sigma == 0.01 else 0.0, (3.0 if precision == "fp32" else 5.0) * floor), (sigma, k, got, floor)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("R", [70, 56, 224])
+def test_fused_patch_embed_matches_the_explicit_im2col_path(G, precision, R, monkeypatch):
+    """K1 + K2 as ONE kernel (implicit im2col, patch_embed.hip) against the im2col + GEMM pair it replaces
+    (DINODET_NO_FUSED_PATCH=1 at weight-pack time): same products, a different fp32 summation order -> 1e-6; and against the
+    reference's embeddings (golden G0) where a fixture exists."""
+    from dinov2_od_amd.models import DINOv2Backbone
+    bb = cases.micro_bb(False) if R != 224 else cases.cfg1(25)[0]
+    sd = synth.backbone_state_dict(bb, seed=1, prefix="")
+    x = G.to_gpu(synth.make_pixels(3, R, R, seed=0))
+    N = num_tokens(R, R)
+    embs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("DINODET_NO_FUSED_PATCH", "1")
+        m = DINOv2Backbone("micro" if R != 224 else "facebook/dinov2-small", lora_r=bb.lora_r, lora_alpha=1.0, target_dim=bb.target_dim or None,
+                           pretrained=False, precision=precision, config=bb)
+        G.load_np_state(m, sd)
+        m = m.to(G.dev()).eval()
+        tap = m._get_engine().set_tap(0, (3, N, bb.hidden), "cuda:0")
+        m(x)
+        G.sync()
+        embs[fused] = tap.cpu().numpy().copy()
+    e = rel_err(embs[True], embs[False])
+    print(f"fused vs explicit patch embed R={R} {precision}: {e:.2e}")
+    assert e < 2e-6
+    if R != 224:
+        g = cases.golden("g0_micro_backbone")
+        assert rel_err(embs[True][:2], g[f"embeddings_{R}"]) < (1e-5 if precision == "bf16x3" else 3e-3)

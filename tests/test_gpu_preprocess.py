@@ -63,3 +63,26 @@ def test_accepts_torch_and_pil_inputs_and_rejects_bad_ones(pre):
         pre.preprocess_batch([im[:, :, :1]], (32, 32))
     with pytest.raises(ValueError):
         pre.preprocess_batch([np.zeros((4000, 4000, 3), np.uint8)], (32, 32))       # > 15x down-scaling: filter wider than PP_MAXK
+
+
+def test_uint8_pipeline_feeds_the_fused_patch_embed_bit_exactly(pre):
+    """f4 fused into K1: the resampled bytes (uint8 HWC, Pillow-exact) go straight into the patch-embedding kernel, which applies
+    ToTensor's / 255 in its load stage -- same detections, bit for bit, as the fp32 CHW batch through the same model"""
+    from PIL import Image
+    from dinov2_od_amd import synth
+    from tests import cases, gpu_util as G
+    imgs = _imgs([(480, 640), (333, 500), (100, 80)], 5)
+    u8 = pre.preprocess_batch(imgs, (224, 224), as_uint8=True)
+    assert u8.dtype == torch.uint8 and u8.shape == (3, 224, 224, 3)
+    for i, im in enumerate(imgs):
+        assert np.array_equal(u8[i].cpu().numpy(), np.array(Image.fromarray(im, "RGB").resize((224, 224), Image.BILINEAR)))
+    f32 = pre.preprocess_batch(imgs, (224, 224))
+    bb, dc = cases.cfg1(25)
+    for precision in ("bf16x3", "bf16"):
+        m = G.make_detector(bb, dc, precision, "facebook/dinov2-small")
+        a = m.forward_packed(f32).clone()
+        b = m.forward_packed_u8(u8).clone()
+        assert torch.equal(a, b), precision
+    m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-small")
+    with pytest.raises(ValueError, match="fused patch embed"):
+        m.forward_packed_u8(u8)                          # exact-fp32 mode keeps the explicit im2col + fp32 GEMM

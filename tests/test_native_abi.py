@@ -44,6 +44,27 @@ def test_config_struct_layout_matches_header():
     assert C.sizeof(nat.DodConfig) == 4 * len(fields)
 
 
+def test_dec_train_params_struct_matches_header():
+    """struct dod_dec_train_params (native decoder training step): the ctypes mirror lists the header's pointers in order"""
+    hdr = open(os.path.join(ROOT, "include", "dinodet.h")).read()
+    body = re.search(r"typedef struct dod_dec_train_params \{(.*?)\} dod_dec_train_params;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\*\s*(\w+)", body)
+    assert names == nat.DEC_TRAIN_FIELDS and len(names) == 31
+    assert C.sizeof(nat.DodDecTrainParams) == 31 * C.sizeof(C.c_void_p)
+
+
+def test_decoder_train_entry_points_validate_arguments(lib):
+    bb, dc = cases.cfg1(25)
+    cfg = make_config(bb, dc, "fp32")
+    assert lib.dod_decoder_train_tape_bytes(C.byref(cfg), 2, 257) > 0 and lib.dod_decoder_train_workspace_bytes(C.byref(cfg), 2, 257) > 0
+    assert lib.dod_decoder_train_tape_bytes(C.byref(cfg), 0, 257) == 0
+    dense = make_config(bb, cases.dec_cfg(False), "fp32")
+    assert lib.dod_decoder_train_tape_bytes(C.byref(dense), 2, 257) == 0            # nn.TransformerDecoder branch: not native
+    rc = lib.dod_decoder_train_forward(C.byref(cfg), None, None, 2, 257, 0.1, 1, None, None, 0, None, 0, None)
+    assert rc == 1 and b"null" in lib.dod_decoder_train_last_error()
+
+
 def test_create_validates_arguments(lib):
     bb, dc = cases.cfg1(25)
     h = C.c_void_p()
