@@ -590,7 +590,7 @@ def test_fused_patch_embed_matches_the_explicit_im2col_path(G, precision, R, mon
         embs[fused] = tap.cpu().numpy().copy()
     e = rel_err(embs[True], embs[False])
     print(f"fused vs explicit patch embed R={R} {precision}: {e:.2e}")
-    assert e < 2e-6
+    assert e < (2e-6 if precision == "bf16" else 1e-5)      # split products: 2^-18 class either way
     if R != 224:
         g = cases.golden("g0_micro_backbone")
         assert rel_err(embs[True][:2], g[f"embeddings_{R}"]) < (1e-5 if precision == "bf16x3" else 3e-3)
