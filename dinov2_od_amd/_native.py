@@ -45,6 +45,20 @@ class DodDecTrainParams(C.Structure):
     _fields_ = [(f, C.c_void_p) for f in DEC_TRAIN_FIELDS]
 
 
+class DodLoraLinear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("A", C.c_void_p), ("Bm", C.c_void_p)]
+
+
+class DodBbBlockParams(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "ls1", "ls2")] + \
+               [(f, DodLoraLinear) for f in ("q", "k", "v", "o", "fc1", "fc2")]
+
+
+class DodBbTailParams(C.Structure):
+    _fields_ = [("nblocks", C.c_int32), ("reserved", C.c_int32), ("blocks", C.POINTER(DodBbBlockParams)),
+                ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p)]
+
+
 # name -> (restype, argtypes): every symbol include/dinodet.h declares
 SYMBOLS = {
     "dod_create": (_I, [C.POINTER(DodConfig), C.POINTER(_P)]),
@@ -86,6 +100,10 @@ SYMBOLS = {
     "dod_decoder_train_forward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _F, C.c_uint64, _P, _P, _SZ, _P, _SZ, _P]),
     "dod_decoder_train_backward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _F, C.c_uint64, _P, _P, _SZ, _P, _P, _P, _SZ, _P]),
     "dod_decoder_train_last_error": (C.c_char_p, []),
+    "dod_backbone_tail_tape_bytes": (_SZ, [C.POINTER(DodConfig), _I, _I, _I]),
+    "dod_backbone_tail_workspace_bytes": (_SZ, [C.POINTER(DodConfig), _I, _I, _I]),
+    "dod_backbone_tail_train_forward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _P, _P, _SZ, _P, _SZ, _P]),
+    "dod_backbone_tail_train_backward": (_I, [C.POINTER(DodConfig), _P, _I, _I, _P, _P, _SZ, _P, _P, _SZ, _P]),
     "dod_debug_gemm_stamps": (_I, [_P]),
     "dod_debug_attn_stamps": (_I, [_P]),
     "dod_debug_mfma_peak": (_I, [_I, _I, _I, _P, _P]),

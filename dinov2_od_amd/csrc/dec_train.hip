@@ -118,6 +118,26 @@ __global__ void sigmoid_bwd4_kernel(const float* __restrict__ dbox, int ldd, con
   const float sg = box[(size_t)r * ldb + c];
   dz[i] = dbox[(size_t)r * ldd + c] * sg * (1.0f - sg);
 }
+// exact-erf GELU backward (modeling_dinov2.py:288-296): g = dy * (Phi(x) + x phi(x))
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ g, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float x = pre[i];
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    g[i] = dy[i] * (cdf + x * pdf);
+  }
+}
+__global__ void gelu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ h, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) h[i] = gelu_erf(pre[i]);
+}
+// out[i] = a[i] * v[i % D]   (LayerScale on the gradient)
+__global__ void colscale_kernel(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ out, size_t n, int D) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] * v[i % D];
+}
+__global__ void fill_kernel(float* __restrict__ a, float v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = v;
+}
 // dq[q][:] += sum_b d[b][q][:]
 __global__ void batch_sum_kernel(const float* __restrict__ d, float* __restrict__ dq, int B, size_t per) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
@@ -183,7 +203,7 @@ int ln_bwd(const float* x, const float* gamma, const float* dy, float eps, int r
 // ------------------------------------------------------------------------------------------------ multi-head self-attention (Q x Q)
 // nn.MultiheadAttention (deformable_attention.py:195, 233): softmax((q k^T) / sqrt(dh)), dropout on the probabilities, times v.
 // qkv [B*Q, 3*Dd] = [q | k | v], head h at columns h*dh.  One wave per (b, head, query row).
-#define MHA_MAXQ 1024
+#define MHA_MAXQ 1408      // decoder queries, and the 1370 tokens of a 518x518 image in the backbone-tail backward
 __device__ __forceinline__ void mha_row_probs(const float* __restrict__ qkv, int ld, int b, int h, int i, int Q, int Dd, int dh, float scale,
                                               float* __restrict__ sp, int lane) {
   const float* qi = qkv + ((size_t)b * Q + i) * ld + h * dh;
@@ -675,6 +695,223 @@ int dod_decoder_train_backward(const dod_config* cfg, const dod_dec_train_params
   // value projection (computed once for the tied layers: d(values) is the sum over layers)
   TK(lin_bwd_w(sc.dvalues, Dd, memory, Dd, d.M, Dd, Dd, G(grads->vp_w), G(grads->vp_b), sc, s));
   if (d_memory) TK(lin_bwd_x(sc.dvalues, Dd, p->vp_w, d.M, Dd, Dd, d_memory, false, sc, s));
+  return DOD_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================================================
+// Backbone tail: the LoRA-adapted encoder blocks (dinov2_backbone.py:45-51: the last two), the final LayerNorm and the projection
+// (dinov2_backbone.py:33-37, 64-65) in train() mode -- the rest of what `loss.backward()` (train.py:1101) reaches: gradients of every
+// lora_A / lora_B (utils.py:46-70) and of the projection.  The DINOv2 weights, LayerNorms, LayerScales and biases are frozen
+// (dinov2_backbone.py:40-41), and so is everything in front of the first adapted block (it runs in the inference kernels,
+// dod_backbone_prefix): the backward stops at the tail's input.  GELU MLP (ViT-S/B/L).
+//   forward : x -> LN1 -> q|k|v (W' = W + alpha B A, merged in fp32 as the eval path does) -> softmax(q k^T / sqrt(dh)) v -> dense
+//             -> x + ls1 * . -> LN2 -> fc1 -> GELU(erf) -> fc2 -> + ls2 * .  ->  final LN -> projection
+//   backward: dX = dY W' on the fp32 MFMA GEMM; per LoRA linear  dB += alpha dY^T (X A^T),  dA += alpha (dY B)^T X  (rank-r GEMMs);
+//             attention backward = the row / column passes of the decoder's self-attention with Q := N tokens.
+namespace {
+
+struct TDims { int B, N, M, D, H, dh, F, Dd, nb, r; float alpha, eps; };
+bool make_tdims(const dod_config* c, int B, int N, int nblocks, TDims* d) {
+  if (!c || B <= 0 || N <= 0 || nblocks <= 0 || nblocks > 8 || c->swiglu) return false;
+  d->B = B; d->N = N; d->M = B * N; d->D = c->hidden; d->H = c->heads; d->dh = d->D / d->H; d->F = c->ffn_hidden;
+  d->Dd = c->target_dim ? c->target_dim : c->hidden; d->nb = nblocks; d->r = c->lora_r; d->alpha = c->lora_alpha; d->eps = c->ln_eps;
+  if (d->D % d->H || d->dh > 128 || d->dh % 4 || d->D % 4 || d->F % 4 || d->D > 1024 * 16 || N > MHA_MAXQ || d->r < 1 || d->r > 64) return false;
+  return true;
+}
+struct TTape {
+  float* xout; float* f;
+  struct Blk { float *x, *y1, *qkv, *ctx, *x1, *y2, *pre, *h, *Wqkv, *Wo, *W1, *W2, *bqkv; } b[8];
+};
+size_t carve_ttape(const TDims& d, void* base, TTape* t) {
+  size_t off = 0;
+  auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr; off += al256(n * 4); return p; };
+  const size_t M = d.M, D = d.D, F = d.F;
+  TTape tt;
+  tt.xout = take(M * D); tt.f = take(M * D);
+  for (int i = 0; i < d.nb; ++i) {
+    auto& b = tt.b[i];
+    b.x = take(M * D); b.y1 = take(M * D); b.qkv = take(M * 3 * D); b.ctx = take(M * D); b.x1 = take(M * D); b.y2 = take(M * D);
+    b.pre = take(M * F); b.h = take(M * F);
+    b.Wqkv = take(3 * D * D); b.Wo = take(D * D); b.W1 = take(F * D); b.W2 = take(D * F); b.bqkv = take(3 * D);
+  }
+  if (t) *t = tt;
+  return off;
+}
+struct TScratch { float *dx, *da, *db, *dbig, *dqkv, *dS, *Pd, *T, *U, *avec, *dump, *tY, *tX, *wT, *padY; };
+size_t carve_tscratch(const TDims& d, void* base, TScratch* sc) {
+  size_t off = 0;
+  auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr; off += al256(n * 4); return p; };
+  const size_t M = d.M, D = d.D, F = d.F, big = F > 3 * D ? F : 3 * D;
+  TScratch s;
+  s.dx = take(M * D); s.da = take(M * D); s.db = take(M * D); s.dbig = take(M * big); s.dqkv = take(M * 3 * D);
+  s.dS = take((size_t)d.B * d.H * d.N * d.N); s.Pd = take((size_t)d.B * d.H * d.N * d.N);
+  s.T = take(M * up4(d.r)); s.U = take(M * up4(d.r)); s.avec = take(64); s.dump = take(2 * big);
+  s.tY = take(big * up4(M)); s.tX = take(big * up4(M)); s.wT = take(big * D + 64); s.padY = take(M * up4(d.r) + 64);
+  if (sc) *sc = s;
+  return off;
+}
+// the generic linear backward helpers take a Scratch: view a TScratch as one
+Scratch as_scratch(const TScratch& t) { Scratch s; memset(&s, 0, sizeof s); s.tY = t.tY; s.tX = t.tX; s.wT = t.wT; s.padY = t.padY; return s; }
+
+// gradients of one LoRA pair for out = X W'^T: dB [out, r] += alpha dY^T (X A^T), dA [r, in] += alpha (dY B)^T X
+int lora_grads(const TDims& d, const float* X, int in_f, const float* dY, int ldy, int out_f, const float* A, const float* Bm, float* dA, float* dB,
+               const TScratch& t, hipStream_t s) {
+  if (!dA || !dB) return 0;
+  const Scratch sc = as_scratch(t);
+  const int r = d.r, rp = (int)up4(r);
+  GemmEpi e = gepi(nullptr, t.T, rp); e.scale = t.avec;                                   // T = alpha X A^T   [M, r]
+  int rc = launch_gemm_f32(X, in_f, A, in_f, d.M, r, in_f, e, s); if (rc) return rc;
+  rc = lin_bwd_w(dY, ldy, t.T, rp, d.M, out_f, r, dB, nullptr, sc, s); if (rc) return rc;  // dB += dY^T T
+  {                                                                                       // U = alpha dY B   [M, r]
+    const int Np = (int)up4(out_f);
+    if (out_f != Np || ldy % 4) return 2;
+    if (transpose_pad(Bm, r, out_f, r, sc.wT, Np, s)) return 3;                           // B^T [r, out]
+    GemmEpi eu = gepi(nullptr, t.U, rp); eu.scale = t.avec;
+    rc = launch_gemm_f32(dY, ldy, sc.wT, Np, d.M, r, Np, eu, s); if (rc) return rc;
+  }
+  return lin_bwd_w(t.U, rp, X, in_f, d.M, r, in_f, dA, nullptr, sc, s);                    // dA += U^T X
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dod_backbone_tail_tape_bytes(const dod_config* cfg, int B, int N, int nblocks) {
+  TDims d; if (!make_tdims(cfg, B, N, nblocks, &d)) return 0;
+  return carve_ttape(d, nullptr, nullptr) + 256;
+}
+size_t dod_backbone_tail_workspace_bytes(const dod_config* cfg, int B, int N, int nblocks) {
+  TDims d; if (!make_tdims(cfg, B, N, nblocks, &d)) return 0;
+  return carve_tscratch(d, nullptr, nullptr) + 256;
+}
+
+int dod_backbone_tail_train_forward(const dod_config* cfg, const dod_bb_tail_params* p, const float* x_in, int B, int N, float* mem_out,
+                                    void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
+  if (!p || !p->blocks) return tfail(DOD_ERR_INVALID, "backbone tail: null parameters");
+  TDims d;
+  if (!make_tdims(cfg, B, N, p->nblocks, &d)) return tfail(DOD_ERR_INVALID, "backbone tail: unsupported configuration (GELU MLP, head_dim <= 128, N <= %d, 1 <= lora_r <= 64)", MHA_MAXQ);
+  if (!x_in || !mem_out || !tape || !ws) return tfail(DOD_ERR_INVALID, "backbone tail: null buffer");
+  if (tape_bytes < dod_backbone_tail_tape_bytes(cfg, B, N, p->nblocks) || ws_bytes < dod_backbone_tail_workspace_bytes(cfg, B, N, p->nblocks))
+    return tfail(DOD_ERR_STATE, "backbone tail: tape / workspace too small");
+  if (cfg->target_dim && (!p->proj_w || !p->proj_b)) return tfail(DOD_ERR_MISSING, "backbone tail: projection weights missing");
+  hipStream_t s = (hipStream_t)stream;
+  TTape t; TScratch sc;
+  carve_ttape(d, (void*)(((uintptr_t)tape + 255) & ~(uintptr_t)255), &t);
+  carve_tscratch(d, (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &sc);
+  const int M = d.M, D = d.D, F = d.F;
+  const float scale = 1.0f / sqrtf((float)d.dh);
+  TH(hipMemcpyAsync(t.b[0].x, x_in, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+  for (int i = 0; i < d.nb; ++i) {
+    const dod_bb_block_params& bp = p->blocks[i];
+    auto& tb = t.b[i];
+    // merged weights W' = W + alpha B A (utils.py:68-70), q | k | v concatenated
+    const dod_lora_linear* qkv3[3] = {&bp.q, &bp.k, &bp.v};
+    for (int c = 0; c < 3; ++c) {
+      TK(launch_lora_merge(qkv3[c]->w, qkv3[c]->A, qkv3[c]->Bm, d.alpha, D, D, d.r, tb.Wqkv + (size_t)c * D * D, s));
+      TH(hipMemcpyAsync(tb.bqkv + (size_t)c * D, qkv3[c]->b, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+    }
+    TK(launch_lora_merge(bp.o.w, bp.o.A, bp.o.Bm, d.alpha, D, D, d.r, tb.Wo, s));
+    TK(launch_lora_merge(bp.fc1.w, bp.fc1.A, bp.fc1.Bm, d.alpha, F, D, d.r, tb.W1, s));
+    TK(launch_lora_merge(bp.fc2.w, bp.fc2.A, bp.fc2.Bm, d.alpha, D, F, d.r, tb.W2, s));
+    TK(launch_layernorm(tb.x, nullptr, bp.ln1_w, bp.ln1_b, d.eps, M, D, tb.y1, nullptr, s));
+    TK(lin_fwd(tb.y1, D, tb.Wqkv, tb.bqkv, M, 3 * D, D, tb.qkv, 3 * D, ACT_NONE, s));
+    {
+      AttnF32 a; a.q = tb.qkv; a.k = tb.qkv + D; a.v = tb.qkv + 2 * D; a.o = tb.ctx; a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
+      a.Lq = a.Lk = N; a.B = B; a.heads = d.H; a.dh = d.dh; a.scale = scale;
+      TK(launch_attn_f32(a, s));
+    }
+    {   // x1 = x + ls1 * (ctx Wo'^T + bo)
+      GemmEpi e = gepi(bp.o.b, tb.x1, D, ACT_NONE, tb.x, D); e.scale = bp.ls1;
+      TK(launch_gemm_f32(tb.ctx, D, tb.Wo, D, M, D, D, e, s));
+    }
+    TK(launch_layernorm(tb.x1, nullptr, bp.ln2_w, bp.ln2_b, d.eps, M, D, tb.y2, nullptr, s));
+    TK(lin_fwd(tb.y2, D, tb.W1, bp.fc1.b, M, F, D, tb.pre, F, ACT_NONE, s));        // taped: the backward needs the pre-activation
+    {
+      const size_t n = (size_t)M * F;
+      hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, tb.pre, tb.h, n);
+      TH(hipGetLastError());
+    }
+    float* xnext = i + 1 < d.nb ? t.b[i + 1].x : t.xout;
+    {
+      GemmEpi e = gepi(bp.fc2.b, xnext, D, ACT_NONE, tb.x1, D); e.scale = bp.ls2;
+      TK(launch_gemm_f32(tb.h, F, tb.W2, F, M, D, F, e, s));
+    }
+  }
+  if (cfg->target_dim) {
+    TK(launch_layernorm(t.xout, nullptr, p->lnf_w, p->lnf_b, d.eps, M, D, t.f, nullptr, s));
+    TK(lin_fwd(t.f, D, p->proj_w, p->proj_b, M, d.Dd, D, mem_out, d.Dd, ACT_NONE, s));
+  } else {
+    TK(launch_layernorm(t.xout, nullptr, p->lnf_w, p->lnf_b, d.eps, M, D, mem_out, nullptr, s));
+  }
+  return DOD_OK;
+}
+
+int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_params* p, int B, int N, const float* d_mem, const void* tape,
+                                     size_t tape_bytes, const dod_bb_tail_params* grads, void* ws, size_t ws_bytes, void* stream) {
+  if (!p || !p->blocks || !grads || !grads->blocks || grads->nblocks != p->nblocks) return tfail(DOD_ERR_INVALID, "backbone tail: null / mismatched parameters");
+  TDims d;
+  if (!make_tdims(cfg, B, N, p->nblocks, &d)) return tfail(DOD_ERR_INVALID, "backbone tail: unsupported configuration");
+  if (!d_mem || !tape || !ws) return tfail(DOD_ERR_INVALID, "backbone tail: null buffer");
+  if (tape_bytes < dod_backbone_tail_tape_bytes(cfg, B, N, p->nblocks) || ws_bytes < dod_backbone_tail_workspace_bytes(cfg, B, N, p->nblocks))
+    return tfail(DOD_ERR_STATE, "backbone tail: tape / workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  TTape t; TScratch sc;
+  carve_ttape(d, (void*)(((uintptr_t)tape + 255) & ~(uintptr_t)255), &t);
+  carve_tscratch(d, (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &sc);
+  const Scratch gs = as_scratch(sc);
+  auto G = [](const float* q) { return const_cast<float*>(q); };
+  const int M = d.M, D = d.D, F = d.F;
+  const size_t nMD = (size_t)M * D;
+  const float scale = 1.0f / sqrtf((float)d.dh);
+  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, s, sc.avec, d.alpha, 64);
+  TH(hipGetLastError());
+  auto blocks_for = [](size_t n) { return dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)); };
+  // ---- projection + final LayerNorm (frozen affine: its parameter gradients go to a dump)
+  if (cfg->target_dim) {
+    TK(lin_bwd_w(d_mem, d.Dd, t.f, D, M, d.Dd, D, G(grads->proj_w), G(grads->proj_b), gs, s));
+    TK(lin_bwd_x(d_mem, d.Dd, p->proj_w, M, d.Dd, D, sc.da, false, gs, s));
+    TK(ln_bwd(t.xout, p->lnf_w, sc.da, d.eps, M, D, sc.dx, sc.dump, sc.dump + D, s));
+  } else {
+    TK(ln_bwd(t.xout, p->lnf_w, d_mem, d.eps, M, D, sc.dx, sc.dump, sc.dump + D, s));
+  }
+  // sc.dx = d(block output)
+  for (int i = d.nb - 1; i >= 0; --i) {
+    const dod_bb_block_params& bp = p->blocks[i];
+    const dod_bb_block_params& gp = grads->blocks[i];
+    const auto& tb = t.b[i];
+    // x2 = x1 + ls2 * (h W2'^T + b2)
+    hipLaunchKernelGGL(colscale_kernel, blocks_for(nMD), dim3(256), 0, s, sc.dx, bp.ls2, sc.da, nMD, D);                  // da = d(fc2 out)
+    TH(hipGetLastError());
+    TK(lora_grads(d, tb.h, F, sc.da, D, D, bp.fc2.A, bp.fc2.Bm, G(gp.fc2.A), G(gp.fc2.Bm), sc, s));
+    TK(lin_bwd_x(sc.da, D, tb.W2, M, D, F, sc.dbig, false, gs, s));                                                       // d(h)
+    hipLaunchKernelGGL(gelu_bwd_kernel, blocks_for((size_t)M * F), dim3(256), 0, s, sc.dbig, tb.pre, sc.dbig, (size_t)M * F);
+    TH(hipGetLastError());
+    TK(lora_grads(d, tb.y2, D, sc.dbig, F, F, bp.fc1.A, bp.fc1.Bm, G(gp.fc1.A), G(gp.fc1.Bm), sc, s));
+    TK(lin_bwd_x(sc.dbig, F, tb.W1, M, F, D, sc.da, false, gs, s));                                                       // d(y2)
+    TK(ln_bwd(tb.x1, bp.ln2_w, sc.da, d.eps, M, D, sc.db, sc.dump, sc.dump + D, s));
+    TK(add_inplace(sc.dx, sc.db, nMD, s));                                                                                // dx = d(x1)
+    // x1 = x + ls1 * (ctx Wo'^T + bo)
+    hipLaunchKernelGGL(colscale_kernel, blocks_for(nMD), dim3(256), 0, s, sc.dx, bp.ls1, sc.da, nMD, D);
+    TH(hipGetLastError());
+    TK(lora_grads(d, tb.ctx, D, sc.da, D, D, bp.o.A, bp.o.Bm, G(gp.o.A), G(gp.o.Bm), sc, s));
+    TK(lin_bwd_x(sc.da, D, tb.Wo, M, D, D, sc.db, false, gs, s));                                                         // db = d(ctx)
+    const unsigned nb = (unsigned)(((long)B * d.H * N + 3) / 4);
+    hipLaunchKernelGGL(mha_bwd_row_kernel, dim3(nb), dim3(256), 0, s, tb.qkv, 3 * D, sc.db, D, sc.dqkv, sc.dS, sc.Pd, B, N, d.H, D, d.dh, scale, 0.f, 0ull);
+    TH(hipGetLastError());
+    hipLaunchKernelGGL(mha_bwd_col_kernel, dim3(nb), dim3(256), 0, s, tb.qkv, 3 * D, sc.db, D, sc.dqkv, sc.dS, sc.Pd, B, N, d.H, D, d.dh, scale);
+    TH(hipGetLastError());
+    const dod_lora_linear* qkv3[3] = {&bp.q, &bp.k, &bp.v};
+    const dod_lora_linear* gqkv3[3] = {&gp.q, &gp.k, &gp.v};
+    for (int c = 0; c < 3; ++c)
+      TK(lora_grads(d, tb.y1, D, sc.dqkv + (size_t)c * D, 3 * D, D, qkv3[c]->A, qkv3[c]->Bm, G(gqkv3[c]->A), G(gqkv3[c]->Bm), sc, s));
+    if (i > 0) {        // the tail's input is the frozen prefix's output: nothing below block 0 needs a gradient
+      TK(lin_bwd_x(sc.dqkv, 3 * D, tb.Wqkv, M, 3 * D, D, sc.da, false, gs, s));                                           // d(y1)
+      TK(ln_bwd(tb.x, bp.ln1_w, sc.da, d.eps, M, D, sc.db, sc.dump, sc.dump + D, s));
+      TK(add_inplace(sc.dx, sc.db, nMD, s));                                                                              // dx = d(x): the block below's output
+    }
+  }
   return DOD_OK;
 }
 

@@ -140,3 +140,52 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
   }
 }
 
+
+// bf16 outputs without residual / row remap (QKV, fc1; plain or pair layout): EIGHT columns per lane -- one 16-byte store per lane
+// and row instead of two 8-byte ones: the store tail of a tile is bound by the number of store instructions, not by their bytes
+// (guide T21), and a workgroup per CU has nothing else to overlap it with.
+__device__ __forceinline__ bool drain8_ok(const GemmEpi& e, int N) {
+  return e.out_bf16 && e.out_split <= 0 && !e.resid && e.rows_per_img == 0 && !e.a_scale && (N & 7) == 0 && (e.ldc & 7) == 0 &&
+         (e.out_split == 0 || ((-e.out_split) & 7) == 0);
+}
+template <int ROWS, int COLS, int NT, typename RowMap>
+__device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, const GemmEpi& e, int M, int N, int n0, int tid, RowMap rowmap) {
+  constexpr int C8 = COLS / 8;
+  static_assert(NT % C8 == 0, "a thread must keep its column group");
+  const int c8 = tid % C8;
+  const int n = n0 + 8 * c8;
+  if (n >= N) return;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0;
+  if (e.bias) { b0 = *reinterpret_cast<const float4*>(e.bias + n); b1 = *reinterpret_cast<const float4*>(e.bias + n + 4); }
+  if (e.scale) { s0 = *reinterpret_cast<const float4*>(e.scale + n); s1 = *reinterpret_cast<const float4*>(e.scale + n + 4); }
+#pragma unroll
+  for (int row_l = tid / C8; row_l < ROWS; row_l += NT / C8) {
+    const int m = rowmap(row_l);
+    if (m >= M) continue;
+    float4 v = *reinterpret_cast<const float4*>(sm + row_l * pitch + c8 * 32);
+    float4 u = *reinterpret_cast<const float4*>(sm + row_l * pitch + c8 * 32 + 16);
+    v.x += b0.x; v.y += b0.y; v.z += b0.z; v.w += b0.w;
+    u.x += b1.x; u.y += b1.y; u.z += b1.z; u.w += b1.w;
+    if (e.act == ACT_GELU) {
+      v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
+      u.x = gelu_fast(u.x); u.y = gelu_fast(u.y); u.z = gelu_fast(u.z); u.w = gelu_fast(u.w);
+    } else if (e.act == ACT_RELU) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+    }
+    v.x *= s0.x; v.y *= s0.y; v.z *= s0.z; v.w *= s0.w;
+    u.x *= s1.x; u.y *= s1.y; u.z *= s1.z; u.w *= s1.w;
+    uint4 hi;
+    hi.x = pack2bf(v.x, v.y); hi.y = pack2bf(v.z, v.w); hi.z = pack2bf(u.x, u.y); hi.w = pack2bf(u.z, u.w);
+    bf16_t* o = e.out_bf16 + (size_t)m * e.ldc + n;
+    *reinterpret_cast<uint4*>(o) = hi;
+    if (e.out_split < 0) {       // pair layout [hi | lo]
+      uint4 lo;
+      lo.x = pack2bf(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
+      lo.y = pack2bf(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
+      lo.z = pack2bf(u.x - __uint_as_float(hi.z << 16), u.y - __uint_as_float(hi.z & 0xffff0000u));
+      lo.w = pack2bf(u.z - __uint_as_float(hi.w << 16), u.w - __uint_as_float(hi.w & 0xffff0000u));
+      *reinterpret_cast<uint4*>(o - e.out_split) = lo;
+    }
+  }
+}

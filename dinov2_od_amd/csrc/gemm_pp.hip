@@ -149,6 +149,7 @@ __global__ __launch_bounds__(512) void gemm_pp_256x256_kernel(const bf16_t* __re
   // epilogue: two passes of 128 tile rows (64 of each group) through a 128 x 256 fp32 LDS tile (pitch +16 B)
   constexpr int PITCH = PPN * 4 + 16;
   const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
+  const bool wide = drain8_ok(e, N);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     if (pass) __syncthreads();
@@ -162,8 +163,9 @@ __global__ __launch_bounds__(512) void gemm_pp_256x256_kernel(const bf16_t* __re
         *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
       }
     __syncthreads();
-    drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                              [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+    if (wide) drain_tile_bf16x8<128, PPN, 512>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+    else drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid,
+                                   [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
   }
 }
 
@@ -309,6 +311,7 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
 
   constexpr int PITCH = PPN * 4 + 16;
   const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
+  const bool wide = drain8_ok(e, N);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     if (pass) __syncthreads();
@@ -322,8 +325,9 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
         *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
       }
     __syncthreads();
-    drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                              [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+    if (wide) drain_tile_bf16x8<128, PPN, 512>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+    else drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid,
+                                   [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
   }
 }
 

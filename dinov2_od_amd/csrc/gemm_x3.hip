@@ -110,6 +110,7 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
   // epilogue: two passes of 128 tile rows through a 128 x 256 fp32 LDS tile (pitch +16 B)
   constexpr int PITCH = X3N * 4 + 16;
   const ColParams cp = load_col_params<X3N>(e, n0, N, tid);
+  const bool wide = drain8_ok(e, N);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __builtin_amdgcn_s_barrier();
@@ -124,8 +125,9 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
         *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
       }
     __syncthreads();
-    drain_tile<128, X3N, 1024>(smem, PITCH, e, cp, M, N, n0, tid,
-                               [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+    if (wide) drain_tile_bf16x8<128, X3N, 1024>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+    else drain_tile<128, X3N, 1024>(smem, PITCH, e, cp, M, N, n0, tid,
+                                    [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
   }
 }
 

@@ -56,6 +56,10 @@ def backbone_forward(m, pixel_values):
         with torch.no_grad():
             h = m._get_engine().backbone_prefix(pixel_values, m._engine_named(), first_trainable)
         layers = layers[first_trainable:]
+        # the adapted blocks, the final LayerNorm and the projection on the native kernels with their hand-written backward
+        from . import _native_train
+        if os.environ.get("DINODET_NATIVE_TRAIN", "1") != "0" and _native_train.tail_supported(m, layers, h):
+            return _native_train.backbone_tail(m, h, layers)
     else:
         x = emb.patch_embeddings.projection(pixel_values.float()).flatten(2).transpose(1, 2)      # :141-149
         h = torch.cat((emb.cls_token.expand(B, -1, -1), x), dim=1) + _pos_embed(emb.position_embeddings, bb.patch, H, W)

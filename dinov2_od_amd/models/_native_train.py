@@ -104,3 +104,112 @@ def decoder_train(m, src, seed=None):
         seed = (int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) << 20) ^ _seed_counter[0]
     p = m._dropout_p if m.training else 0.0
     return _DecoderTrain.apply(src, cfg, p, seed, *_param_list(m))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# backbone tail: the LoRA-adapted blocks + final LayerNorm + projection (dod_backbone_tail_train_forward / _backward)
+_LORA_SITES = ("q", "k", "v", "o", "fc1", "fc2")
+
+
+def _tail_modules(layer):
+    a = layer.attention
+    return [a.attention.query, a.attention.key, a.attention.value, a.output.dense, layer.mlp.fc1, layer.mlp.fc2]
+
+
+def tail_supported(m, layers, x):
+    """every remaining block carries LoRA on its six linears over a frozen base, nothing else in it trains, GELU MLP, fp32 on the GPU"""
+    bb = m._bb_cfg
+    if not (x.is_cuda and x.dtype == torch.float32 and layers and not bb.swiglu and 1 <= bb.lora_r <= 64 and x.shape[1] <= 1408):
+        return False
+    for L in layers:
+        if not hasattr(L.mlp, "fc1"):
+            return False
+        mods = _tail_modules(L)
+        if not all(hasattr(t, "lora_A") for t in mods):
+            return False
+        frozen = [L.norm1.weight, L.norm1.bias, L.norm2.weight, L.norm2.bias, L.layer_scale1.lambda1, L.layer_scale2.lambda1]
+        frozen += [q for t in mods for q in (t.linear.weight, t.linear.bias)]
+        if any(q.requires_grad for q in frozen) or any(t.alpha != mods[0].alpha for t in mods):
+            return False
+    if any(q.requires_grad for q in m.dino.layernorm.parameters()):
+        return False
+    return True
+
+
+def _tail_structs(m, layers, train_tensors, writable):
+    """struct dod_bb_tail_params over the module's own tensors; `train_tensors` (A, B per site and block, then the projection) is
+    what fills the trainable slots -- the parameters themselves, or the gradient accumulators (then the frozen slots stay NULL)"""
+    blocks = (nat.DodBbBlockParams * len(layers))()
+    it = iter(train_tensors)
+    for bp, L in zip(blocks, layers):
+        if not writable:
+            bp.ln1_w, bp.ln1_b, bp.ln2_w, bp.ln2_b = (L.norm1.weight.data_ptr(), L.norm1.bias.data_ptr(), L.norm2.weight.data_ptr(),
+                                                      L.norm2.bias.data_ptr())
+            bp.ls1, bp.ls2 = L.layer_scale1.lambda1.data_ptr(), L.layer_scale2.lambda1.data_ptr()
+        for site, mod in zip(_LORA_SITES, _tail_modules(L)):
+            ll = getattr(bp, site)
+            if not writable:
+                ll.w, ll.b = mod.linear.weight.data_ptr(), mod.linear.bias.data_ptr()
+            ll.A, ll.Bm = next(it).data_ptr(), next(it).data_ptr()
+    ps = nat.DodBbTailParams()
+    ps.nblocks, ps.blocks = len(layers), blocks
+    if not writable:
+        ps.lnf_w, ps.lnf_b = m.dino.layernorm.weight.data_ptr(), m.dino.layernorm.bias.data_ptr()
+    if m.projection is not None:
+        ps.proj_w, ps.proj_b = next(it).data_ptr(), next(it).data_ptr()
+    return ps, blocks          # keep `blocks` alive as long as `ps`
+
+
+def _tail_trainables(m, layers):
+    out = []
+    for L in layers:
+        for mod in _tail_modules(L):
+            out += [mod.lora_A.weight, mod.lora_B.weight]
+    if m.projection is not None:
+        out += [m.projection.weight, m.projection.bias]
+    return out
+
+
+class _BackboneTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_in, m, layers, cfg, *train):
+        L = nat.lib()
+        B, N, _ = x_in.shape
+        x_in = x_in.contiguous()
+        train = [t.detach().contiguous() for t in train]
+        nb = len(layers)
+        with torch.cuda.device(x_in.device):
+            tape = torch.empty(L.dod_backbone_tail_tape_bytes(C.byref(cfg), B, N, nb), dtype=torch.uint8, device=x_in.device)
+            ws = torch.empty(L.dod_backbone_tail_workspace_bytes(C.byref(cfg), B, N, nb), dtype=torch.uint8, device=x_in.device)
+            if tape.numel() == 0 or ws.numel() == 0:
+                raise ValueError("backbone configuration not supported by the native training kernels")
+            mem = torch.empty(B, N, m._bb_cfg.out_dim, dtype=torch.float32, device=x_in.device)
+            ps, keep = _tail_structs(m, layers, train, writable=False)
+            _check(L.dod_backbone_tail_train_forward(C.byref(cfg), C.byref(ps), nat.ptr(x_in), B, N, nat.ptr(mem), nat.ptr(tape), tape.numel(),
+                                                     nat.ptr(ws), ws.numel(), nat.stream_ptr()))
+        ctx.save_for_backward(tape, *train)
+        ctx.m, ctx.layers, ctx.cfg, ctx.ws, ctx.shape = m, layers, cfg, ws, (B, N)
+        return mem
+
+    @staticmethod
+    def backward(ctx, d_mem):
+        L = nat.lib()
+        tape, *train = ctx.saved_tensors
+        B, N = ctx.shape
+        d_mem = d_mem.contiguous().float()
+        with torch.cuda.device(d_mem.device):
+            grads = [torch.zeros_like(t) for t in train]
+            ps, keep1 = _tail_structs(ctx.m, ctx.layers, train, writable=False)
+            gs, keep2 = _tail_structs(ctx.m, ctx.layers, grads, writable=True)
+            _check(L.dod_backbone_tail_train_backward(C.byref(ctx.cfg), C.byref(ps), B, N, nat.ptr(d_mem), nat.ptr(tape), tape.numel(), C.byref(gs),
+                                                      nat.ptr(ctx.ws), ctx.ws.numel(), nat.stream_ptr()))
+        return (None, None, None, None, *grads)
+
+
+def backbone_tail(m, x_in, layers):
+    """residual stream in front of the first LoRA-adapted block -> decoder memory [B, N, out_dim], with the autograd edge to the
+    native backward (gradients of lora_A / lora_B and of the projection)"""
+    from ..config import DecoderConfig
+    dc = getattr(m, "_dc_cfg", None) or DecoderConfig()
+    cfg = make_config(m._bb_cfg, dc, "fp32")
+    return _BackboneTail.apply(x_in, m, list(layers), cfg, *_tail_trainables(m, layers))

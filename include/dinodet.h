@@ -264,6 +264,33 @@ int dod_decoder_train_backward(const dod_config* cfg, const dod_dec_train_params
                                void* stream);
 const char* dod_decoder_train_last_error(void);
 
+/* The rest of the trainable subset: the LoRA-adapted encoder blocks (the last two, dinov2_backbone.py:45-51), the final
+ * LayerNorm and the projection (dinov2_backbone.py:33-37, 64-65) in train() mode.  x_in [B, N, D] is the residual stream in
+ * front of the first adapted block (dod_backbone_prefix: everything before it is frozen and needs no autograd); the forward
+ * writes the decoder memory [B, N, Dd] and tapes its activations, the backward turns d(memory) into the gradients of every
+ * lora_A / lora_B (dino_detector/utils.py:46-70) and of the projection.  Frozen tensors (w, b, LayerNorm, LayerScale) are read
+ * only; in `grads` only A, Bm, proj_w, proj_b are written (float accumulators, same layout).  GELU-MLP variants (ViT-S/B/L);
+ * errors through dod_decoder_train_last_error(). */
+typedef struct dod_lora_linear { const float *w, *b, *A, *Bm; } dod_lora_linear;        /* [out,in], [out], [r,in], [out,r] */
+typedef struct dod_bb_block_params {
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ls1, *ls2;                              /* frozen */
+  dod_lora_linear q, k, v, o, fc1, fc2;                                                /* attention.attention.{query,key,value}, attention.output.dense, mlp.fc1, mlp.fc2 */
+} dod_bb_block_params;
+typedef struct dod_bb_tail_params {
+  int32_t nblocks, reserved;
+  const dod_bb_block_params* blocks;             /* HOST array of nblocks entries (device pointers inside) */
+  const float *lnf_w, *lnf_b;                    /* final LayerNorm (frozen) */
+  const float *proj_w, *proj_b;                  /* [Dd, D], [Dd]; NULL when the backbone has no projection */
+} dod_bb_tail_params;
+size_t dod_backbone_tail_tape_bytes(const dod_config* cfg, int B, int N, int nblocks);
+size_t dod_backbone_tail_workspace_bytes(const dod_config* cfg, int B, int N, int nblocks);
+int dod_backbone_tail_train_forward(const dod_config* cfg, const dod_bb_tail_params* params, const float* x_in, int B, int N,
+                                    float* memory_out, void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                                    void* stream);
+int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_params* params, int B, int N, const float* d_memory,
+                                     const void* tape, size_t tape_bytes, const dod_bb_tail_params* grads, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+
 /* Tuning aid: when dev_buf is non-NULL the large bf16 GEMM kernel stores 4 x uint64 per workgroup
  * {realtime at start, after the K loop, at exit, blockIdx} (100 MHz s_memrealtime); NULL switches it off.
  * Used by tools/gemm_timeline.py. */

@@ -172,3 +172,43 @@ def test_detector_train_step_uses_the_native_decoder_backward():
     assert set(g0) == set(g1) and any("lora_A" in k for k in g1) and any(k.startswith("backbone.projection") for k in g1)
     for k in g0:
         assert rel_err(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-3, k      # LoRA grads pass through two blocks of fp32 autograd
+
+
+@pytest.mark.parametrize("variant,R,B", [("micro", 70, 3), ("small", 224, 2), ("base", 224, 2)])
+def test_native_backbone_tail_backward_matches_composite_autograd(variant, R, B):
+    """The LoRA-adapted blocks + final LayerNorm + projection (dod_backbone_tail_train_*): memory and the gradients of every
+    lora_A / lora_B and of the projection against the composite's autograd on the same frozen-prefix output."""
+    from dinov2_od_amd.config import BackboneConfig
+    from dinov2_od_amd.models import DINOv2Backbone
+    from tests import gpu_util as G
+    if variant == "micro":
+        bb = cases.micro_bb(False)
+        bb.target_dim = 64
+    else:
+        bb = BackboneConfig.from_name(f"facebook/dinov2-{variant}", lora_r=2, lora_alpha=1.0, target_dim=256)
+    m = DINOv2Backbone(variant, lora_r=bb.lora_r, lora_alpha=bb.lora_alpha, target_dim=bb.target_dim, pretrained=False, precision="fp32", config=bb)
+    G.load_np_state(m, synth.backbone_state_dict(bb, seed=1, prefix=""))
+    m = m.to(G.dev()).train()
+    x = G.to_gpu(synth.make_pixels(B, R, R, seed=0))
+    N = (R // 14) ** 2 + 1
+    wgt = G.to_gpu(synth.normal(7, f"tail.w.{variant}", (B, N, bb.target_dim), 1.0))
+
+    def run(native):
+        os.environ["DINODET_NATIVE_TRAIN"] = "1" if native else "0"
+        try:
+            m.zero_grad(set_to_none=True)
+            mem = m(x)
+            (mem * wgt).sum().backward()
+            return mem.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        finally:
+            os.environ.pop("DINODET_NATIVE_TRAIN", None)
+    m0, g0 = run(False)
+    m1, g1 = run(True)
+    assert rel_err(m1.cpu().numpy(), m0.cpu().numpy()) < 2e-5
+    assert set(g0) == set(g1) and sum("lora_A" in k for k in g1) == 12 and "projection.weight" in g1
+    worst = ("", 0.0)
+    for k in g0:
+        e = rel_err(g1[k].cpu().numpy(), g0[k].cpu().numpy())
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 1e-4, (k, e)
+    print(f"backbone tail {variant} R={R}: memory {rel_err(m1.cpu().numpy(), m0.cpu().numpy()):.2e}, worst gradient {worst[0]} {worst[1]:.2e}")
