@@ -262,7 +262,7 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
     h->Kp = is_bf16(h) ? (K + 63) / 64 * 64 : K;
     if (W) h->Wpatch = P.pack_operand(W->ptr, D, K, h->Kp);
     h->Wpe = nullptr;
-    if (W && (is_bf16(h) || is_x3(h)) && p >= 2 && p <= 16 && p % 2 == 0 && D % 4 == 0 && !getenv("DINODET_NO_FUSED_PATCH")) {
+    if (W && (is_bf16(h) || is_x3(h)) && (p == 14 || p == 16) && D % 4 == 0 && !getenv("DINODET_NO_FUSED_PATCH")) {
       bf16_t* wp = P.alloc<bf16_t>((size_t)D * 3 * (p / 2) * 32 * (is_x3(h) ? 2 : 1));
       if (wp && !launch_patch_pack(W->ptr, D, p, wp, is_x3(h) ? 1 : 0, s)) h->Wpe = wp;
     }
@@ -517,8 +517,8 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   int rc = prepare_impl(h, H, W, s); if (rc) return rc;
   // K1 + K2.  Fused form (patch_embed.hip): implicit im2col in the GEMM's load stage, bias + position add in its epilogue; the
   // uint8 HWC input of the device input pipeline (dod_forward_u8) exists only there.
-  if (pixels_u8 && !h->Wpe) return fail(h, DOD_ERR_INVALID, "uint8 input needs the fused patch embed (bf16 / bf16x3 / fp8 precision, even patch size <= 16)");
-  if (h->Wpe) {
+  if (pixels_u8 && !h->Wpe) return fail(h, DOD_ERR_INVALID, "uint8 input needs the fused patch embed (bf16 / bf16x3 / fp8 precision, patch size 14 or 16)");
+  if (h->Wpe && (pixels_u8 || W % 2 == 0)) {
     ProfScope ps(h, s, PC_GEMM_BF16, 2.0 * B * Np * (double)D * 3.0 * p * p);
     KCHK(h, launch_patch_embed(pixels_u8 ? (const void*)pixels_u8 : (const void*)pixels, pixels_u8 ? 1 : 0, B, H, W, p, h->Wpe, is_x3(h) ? 1 : 0,
                                h->bpatch, h->pos_hw, ws.x, D, s));

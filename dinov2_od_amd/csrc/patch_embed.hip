@@ -9,8 +9,8 @@
 //
 // K is walked in steps of TWO pixel rows of one channel: k' = r*16 + j (r = 0, 1; j < p <= 16, zero padded), 3*p/2 steps (21 at
 // p = 14); the weight is packed to that order at load time.  Tile: 128 patches x 128 channels, 4 waves (2 x 2 of 64 x 64,
-// v_mfma_f32_16x16x32_bf16, product computed transposed as in the GEMMs), two LDS stages: the pixel rows of step s+1 are in
-// flight in registers and the weight slice by LDS-DMA while step s feeds the MFMAs.
+// v_mfma_f32_16x16x32_bf16, product computed transposed as in the GEMMs), two LDS stages fed from a three-step-deep register ring
+// (pixels AND weight slice: the loads of steps s+1 .. s+3 are in flight while step s feeds the MFMAs).
 //   X3 = false: bf16 operands (bf16 / fp8 modes);  X3 = true: split products on hi / lo planes (parity-gated bf16x3 mode):
 //   pixel = hi + lo in registers, weight in the pair layout [Wh | Wl], Wl Ah + Wh Al + Wh Ah.
 #include "dod_common.h"
@@ -21,10 +21,12 @@
 
 __device__ __forceinline__ int pe_swz(int row, int chunk) { return chunk ^ (((row >> 3) & 1) << 1); }
 
-template <bool X3, bool U8>
+template <bool X3, bool U8, int P>
 __global__ __launch_bounds__(256) void patch_embed_kernel(const void* __restrict__ img_, const bf16_t* __restrict__ Wp, int ldw,
                                                           const float* __restrict__ bias, const float* __restrict__ pos,
-                                                          float* __restrict__ out, int B, int H, int W, int p, int gh, int gw, int D) {
+                                                          float* __restrict__ out, int B, int H, int W, int gh, int gw, int D) {
+  constexpr int p = P;                                  // compile-time: every pass below is unconditional (a runtime bound makes hipcc
+                                                        // branch around each load and wait for it alone)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NPL = X3 ? 4 : 2;                      // planes per stage: A(h) [, A(l)], W(h) [, W(l)]
   constexpr int STAGE = NPL * PE_PLANE;
@@ -33,75 +35,83 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const void* __restrict
   const int wm = wu >> 1, wn = wu & 1;
   const int Np = gh * gw, Mtot = B * Np;
   const int tiles_m = (Mtot + PE_M - 1) / PE_M;
-  const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;       // consecutive blocks walk M for one weight panel
+  // consecutive blocks share a patch tile (all n-tiles of it run together: the pixels are fetched from HBM once, the whole packed
+  // weight -- 1 MB at D = 768 -- stays in L2 anyway)
+  const int tiles_n = (D + PE_N - 1) / PE_N;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  (void)tiles_m;
   const int m0 = tm * PE_M, n0 = tn * PE_N;
   const int nsteps = 3 * (p / 2), kp = nsteps * 32;
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
 
-  // ---- A gather: thread -> (patch pl = tid >> 1, pixel row r = tid & 1) of the step's row pair
-  const int pl = tid >> 1, r = tid & 1;
-  size_t pix0;                                          // element offset of img[b][0][py*p + r][px*p] (channel 0, row pair 0)
-  size_t cstride, rstride;                              // per channel / per pixel row
-  {
+  // ---- A gather.  Per step the tile needs 2 pixel rows x 128 patches x p pixels; element e = (r * 128 + pl) * p + j is fetched by
+  // thread e % 256 in pass e / 256, so a wave instruction reads 64 CONSECUTIVE pixels of an image row (patches that follow each
+  // other in a patch row are contiguous there) -- and is scattered to its [patch][k' = r*16 + j] slot in LDS as one bf16.
+  // passes: pixel PAIRS (2 * 128 * p / 2) / 256 = p / 2 exactly, every thread owns one pair (8-byte load: p and W even keep it
+  // aligned; a dword per lane made the kernel bound by the number of vector-memory instructions) per pass
+  constexpr int NP2 = P / 2;
+  unsigned goff[NP2];                                   // element offset of (channel 0, row pair 0), per pass (images < 4 G elements)
+  int lofs[NP2];                                        // LDS byte offset inside the A plane, per pass
+  size_t cstride, rstride;
+  if (U8) { cstride = 1; rstride = (size_t)W * 3; } else { cstride = (size_t)H * W; rstride = (size_t)W; }
+#pragma unroll
+  for (int i = 0; i < NP2; ++i) {
+    const int e = tid + 256 * i;
+    const int rr = e / (PE_M * NP2), rem_e = e - rr * (PE_M * NP2), pl = rem_e / NP2, j = 2 * (rem_e - pl * NP2);
     int m = m0 + pl; m = m < Mtot ? m : Mtot - 1;
     const int b = m / Np, rem = m - b * Np, py = rem / gw, px = rem - py * gw;
-    if (U8) {                                           // HWC bytes: ((b*H + y)*W + x)*3 + c
-      pix0 = (((size_t)b * H + (size_t)py * p + r) * W + (size_t)px * p) * 3;
-      cstride = 1; rstride = (size_t)W * 3;
-    } else {                                            // CHW floats
-      pix0 = (((size_t)b * 3) * H + (size_t)py * p + r) * W + (size_t)px * p;
-      cstride = (size_t)H * W; rstride = (size_t)W;
-    }
+    if (U8) goff[i] = (unsigned)((((size_t)b * H + (size_t)py * p + rr) * W + (size_t)px * p + j) * 3);
+    else goff[i] = (unsigned)((((size_t)b * 3) * H + (size_t)py * p + rr) * W + (size_t)px * p + j);
+    const int kq = rr * 16 + j;                         // k' of the pair's first pixel (even: both sit in one 16-byte chunk)
+    lofs[i] = pl * 64 + pe_swz(pl, kq >> 3) * 16 + (kq & 7) * 2;
   }
-  float pv[16];
-  auto gload = [&](int s) {
-    const int c = s / (p / 2), si = s - c * (p / 2);
-    const size_t o = pix0 + c * cstride + (size_t)(2 * si) * rstride;
-    if (U8) {
-      const unsigned char* q = (const unsigned char*)img_ + o;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) pv[j] = j < p ? (float)q[3 * j] / 255.0f : 0.f;      // ToTensor
-    } else {
-      const float* q = (const float*)img_ + o;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) pv[j] = j < p ? q[j] : 0.f;
-    }
-  };
-  auto awrite = [&](int stage) {
-    char* sa = smem + stage * STAGE;
-    uint4 h0, h1;
-    h0.x = pack2bf(pv[0], pv[1]); h0.y = pack2bf(pv[2], pv[3]); h0.z = pack2bf(pv[4], pv[5]); h0.w = pack2bf(pv[6], pv[7]);
-    h1.x = pack2bf(pv[8], pv[9]); h1.y = pack2bf(pv[10], pv[11]); h1.z = pack2bf(pv[12], pv[13]); h1.w = pack2bf(pv[14], pv[15]);
-    const int o0 = pl * 64 + pe_swz(pl, 2 * r) * 16, o1 = pl * 64 + pe_swz(pl, 2 * r + 1) * 16;
-    *reinterpret_cast<uint4*>(sa + o0) = h0;
-    *reinterpret_cast<uint4*>(sa + o1) = h1;
-    if (X3) {
-      auto lo2 = [](float a, float b, unsigned hi) { return pack2bf(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)); };
-      uint4 l0, l1;
-      l0.x = lo2(pv[0], pv[1], h0.x); l0.y = lo2(pv[2], pv[3], h0.y); l0.z = lo2(pv[4], pv[5], h0.z); l0.w = lo2(pv[6], pv[7], h0.w);
-      l1.x = lo2(pv[8], pv[9], h1.x); l1.y = lo2(pv[10], pv[11], h1.y); l1.z = lo2(pv[12], pv[13], h1.z); l1.w = lo2(pv[14], pv[15], h1.w);
-      *reinterpret_cast<uint4*>(sa + PE_PLANE + o0) = l0;
-      *reinterpret_cast<uint4*>(sa + PE_PLANE + o1) = l1;
-    }
-  };
-  // ---- W slice by LDS-DMA: per plane each wave issues two 16-row pieces
-  const bf16_t *gW0, *gW1;
+  // Register ring, three steps deep: the loads of steps s+1 .. s+3 are in flight while step s computes -- a step is only 16 (48)
+  // MFMAs per wave, far shorter than a memory round trip, so one step of prefetch left the kernel latency-bound (3.5 us per step).
+  // The weight slice goes through registers too (plain loads: beside an LDS-DMA in flight hipcc would wait vmcnt(0) for every
+  // ordinary load and drain the ring each step).
+  // (macros over plain locals: arrays of uint4 handed to lambdas by reference stayed in scratch)
+  float pv0[P], pv1[P], pv2[P];
+  uint4 wA0, wB0, wC0, wD0, wA1, wB1, wC1, wD1, wA2, wB2, wC2, wD2;       // per ring slot: W(h) halves [, W(l) halves]
+  // W slice: thread -> row (tid >> 1), 32-byte half (tid & 1) of the step's 64-byte row
+  const bf16_t* gWr;
+  int wofs0, wofs1;
   {
-    const int rl = wid * 32 + (lane >> 2);
-    const int c = pe_swz(rl, lane & 3);
-    int r0 = n0 + rl, r1 = n0 + rl + 16; r0 = r0 < D ? r0 : D - 1; r1 = r1 < D ? r1 : D - 1;
-    gW0 = Wp + (size_t)r0 * ldw + c * 8; gW1 = Wp + (size_t)r1 * ldw + c * 8;
+    const int rl = tid >> 1, hf = tid & 1;
+    int rr = n0 + rl; rr = rr < D ? rr : D - 1;
+    gWr = Wp + (size_t)rr * ldw + hf * 16;
+    wofs0 = rl * 64 + pe_swz(rl, 2 * hf) * 16;
+    wofs1 = rl * 64 + pe_swz(rl, 2 * hf + 1) * 16;
   }
-  auto wstage = [&](int stage, int s) {
-    char* d = smem + stage * STAGE + (X3 ? 2 : 1) * PE_PLANE + wu * 2048;
-    __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + s * 32), (lptr_t)(d), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(gW1 + s * 32), (lptr_t)(d + 1024), 16, 0, 0);
-    if (X3) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + kp + s * 32), (lptr_t)(d + PE_PLANE), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(gW1 + kp + s * 32), (lptr_t)(d + PE_PLANE + 1024), 16, 0, 0);
-    }
-  };
+#define PE_GLOAD(PV, WA, WB, WC, WD, s_)                                                                    \
+  {                                                                                                         \
+    const int c_ = (s_) / (p / 2), si_ = (s_) - c_ * (p / 2);                                               \
+    const size_t o_ = c_ * cstride + (size_t)(2 * si_) * rstride;                                           \
+    _Pragma("unroll") for (int i = 0; i < NP2; ++i) {                                                       \
+      if (U8) {                                                                                             \
+        const unsigned char* q_ = (const unsigned char*)img_ + goff[i] + o_;                                \
+        PV[2 * i] = (float)q_[0] / 255.0f; PV[2 * i + 1] = (float)q_[3] / 255.0f;   /* ToTensor */           \
+      } else {                                                                                              \
+        const float2 v_ = *reinterpret_cast<const float2*>((const float*)img_ + goff[i] + o_);              \
+        PV[2 * i] = v_.x; PV[2 * i + 1] = v_.y;                                                             \
+      }                                                                                                     \
+    }                                                                                                       \
+    const uint4* wp_ = reinterpret_cast<const uint4*>(gWr + (s_) * 32);                                     \
+    WA = wp_[0]; WB = wp_[1];                                                                               \
+    if (X3) { const uint4* wq_ = reinterpret_cast<const uint4*>(gWr + kp + (s_) * 32); WC = wq_[0]; WD = wq_[1]; } \
+  }
+#define PE_SWRITE(PV, WA, WB, WC, WD, stage_)                                                               \
+  {                                                                                                         \
+    char* sa_ = smem + (stage_) * STAGE;                                                                    \
+    _Pragma("unroll") for (int i = 0; i < NP2; ++i) {                                                       \
+      const unsigned hi_ = pack2bf(PV[2 * i], PV[2 * i + 1]);                                               \
+      *reinterpret_cast<unsigned*>(sa_ + lofs[i]) = hi_;                                                    \
+      if (X3) *reinterpret_cast<unsigned*>(sa_ + PE_PLANE + lofs[i]) =                                      \
+          pack2bf(PV[2 * i] - __uint_as_float(hi_ << 16), PV[2 * i + 1] - __uint_as_float(hi_ & 0xffff0000u)); \
+    }                                                                                                       \
+    char* sw_ = sa_ + (X3 ? 2 : 1) * PE_PLANE;                                                              \
+    *reinterpret_cast<uint4*>(sw_ + wofs0) = WA;                                                            \
+    *reinterpret_cast<uint4*>(sw_ + wofs1) = WB;                                                            \
+    if (X3) { *reinterpret_cast<uint4*>(sw_ + PE_PLANE + wofs0) = WC; *reinterpret_cast<uint4*>(sw_ + PE_PLANE + wofs1) = WD; } \
+  }
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -115,14 +125,14 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const void* __restrict
 #pragma unroll
   for (int j = 0; j < 4; ++j) { const int row = wn * 64 + j * 16 + l15; offW[j] = (X3 ? 2 : 1) * PE_PLANE + row * 64 + pe_swz(row, l4) * 16; }
 
-  gload(0);
-  wstage(0, 0);
-  awrite(0);
-  __syncthreads();            // drains the DMA (vmcnt(0)) and publishes the A tile
-  for (int s = 0; s < nsteps; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < nsteps) { gload(s + 1); wstage(cur ^ 1, s + 1); }
-    const char* st = smem + cur * STAGE;
+  // the padding columns j = p..15 of the A planes are never written: zero both stages once
+  for (int i = tid; i < 2 * STAGE / 16; i += 256) {
+    const int st_ = i / (STAGE / 16), o_ = (i - st_ * (STAGE / 16)) * 16;
+    if (o_ < (X3 ? 2 : 1) * PE_PLANE) *reinterpret_cast<uint4*>(smem + st_ * STAGE + o_) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  auto compute = [&](int stage) {
+    const char* st = smem + stage * STAGE;
     bf16x8 wh[4], wl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -143,7 +153,26 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const void* __restrict
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah, acc[i][j], 0, 0, 0);
       }
     }
-    if (s + 1 < nsteps) awrite(cur ^ 1);
+  };
+  // nsteps = 3 * (p / 2) is a multiple of 3: step s lives in ring register s % 3 and LDS stage s & 1
+  PE_GLOAD(pv0, wA0, wB0, wC0, wD0, 0)
+  PE_GLOAD(pv1, wA1, wB1, wC1, wD1, 1)
+  PE_GLOAD(pv2, wA2, wB2, wC2, wD2, 2)
+  PE_SWRITE(pv0, wA0, wB0, wC0, wD0, 0)
+  __syncthreads();
+  for (int s = 0; s < nsteps; s += 3) {
+    // step s: ring slot 0 (its data went to LDS during step s - 1) is refilled with step s + 3; slot 1 goes to LDS for step s + 1
+    if (s + 3 < nsteps) PE_GLOAD(pv0, wA0, wB0, wC0, wD0, s + 3)
+    compute(s & 1);
+    PE_SWRITE(pv1, wA1, wB1, wC1, wD1, (s + 1) & 1)
+    __syncthreads();
+    if (s + 4 < nsteps) PE_GLOAD(pv1, wA1, wB1, wC1, wD1, s + 4)
+    compute((s + 1) & 1);
+    PE_SWRITE(pv2, wA2, wB2, wC2, wD2, (s + 2) & 1)
+    __syncthreads();
+    if (s + 5 < nsteps) PE_GLOAD(pv2, wA2, wB2, wC2, wD2, s + 5)
+    compute((s + 2) & 1);
+    if (s + 3 < nsteps) PE_SWRITE(pv0, wA0, wB0, wC0, wD0, (s + 3) & 1)
     __syncthreads();
   }
   // ---- epilogue: + bias + position row, rows shifted past the CLS slot
@@ -195,26 +224,21 @@ int launch_patch_pack(const float* W, int D, int p, bf16_t* out, int x3, hipStre
 // img: fp32 [B,3,H,W] (u8 = 0) or uint8 [B,H,W,3] (u8 = 1).  Wp from launch_patch_pack.  out: the residual stream x [B, Np+1, D].
 int launch_patch_embed(const void* img, int u8, int B, int H, int W, int p, const bf16_t* Wp, int x3, const float* bias, const float* pos,
                        float* out, int D, hipStream_t s) {
-  if (p < 2 || p > 16 || (p & 1) || D % 4 != 0 || B <= 0) return 2;
+  if ((p != 14 && p != 16) || D % 4 != 0 || B <= 0 || (!u8 && (W & 1))) return 2;      // fp32 rows must keep 8-byte alignment
   const int gh = H / p, gw = W / p;
   if (gh <= 0 || gw <= 0) return 2;
+  if ((size_t)B * 3 * H * W >= 0xffffffffull) return 2;          // 32-bit element offsets
   const int kp = 3 * (p / 2) * 32, ldw = x3 ? 2 * kp : kp;
   const int tiles = (((B * gh * gw) + PE_M - 1) / PE_M) * ((D + PE_N - 1) / PE_N);
   const int lds = 2 * (x3 ? 4 : 2) * PE_PLANE;
-  static bool attr_set[16] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(patch_embed_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PE_PLANE);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(patch_embed_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PE_PLANE);
-    attr_set[dev] = true;
-  }
-  if (x3) {
-    if (u8) hipLaunchKernelGGL((patch_embed_kernel<true, true>), dim3(tiles), dim3(256), lds, s, img, Wp, ldw, bias, pos, out, B, H, W, p, gh, gw, D);
-    else hipLaunchKernelGGL((patch_embed_kernel<true, false>), dim3(tiles), dim3(256), lds, s, img, Wp, ldw, bias, pos, out, B, H, W, p, gh, gw, D);
+#define PE_LAUNCH(X3_, U8_, P_) hipLaunchKernelGGL((patch_embed_kernel<X3_, U8_, P_>), dim3(tiles), dim3(256), lds, s, img, Wp, ldw, bias, pos, out, B, H, W, gh, gw, D)
+  if (p == 14) {
+    if (x3) { if (u8) PE_LAUNCH(true, true, 14); else PE_LAUNCH(true, false, 14); }
+    else { if (u8) PE_LAUNCH(false, true, 14); else PE_LAUNCH(false, false, 14); }
   } else {
-    if (u8) hipLaunchKernelGGL((patch_embed_kernel<false, true>), dim3(tiles), dim3(256), lds, s, img, Wp, ldw, bias, pos, out, B, H, W, p, gh, gw, D);
-    else hipLaunchKernelGGL((patch_embed_kernel<false, false>), dim3(tiles), dim3(256), lds, s, img, Wp, ldw, bias, pos, out, B, H, W, p, gh, gw, D);
+    if (x3) { if (u8) PE_LAUNCH(true, true, 16); else PE_LAUNCH(true, false, 16); }
+    else { if (u8) PE_LAUNCH(false, true, 16); else PE_LAUNCH(false, false, 16); }
   }
+#undef PE_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
