@@ -199,6 +199,11 @@ class Stepper:
                 except Exception as e:                    # capture unsupported -> eager, say so
                     print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
                     self.graph = None
+            if world > 1:
+                # one untimed step incl. the collective: RCCL builds its communicator lazily on the first call (seconds), which must
+                # not land in the timed region even with --warmup 0
+                self()
+                self.sync()
 
     def sync(self):
         if not self.cpu:
