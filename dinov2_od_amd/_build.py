@@ -24,6 +24,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
          "-I" + os.path.join(ROOT, "include")]
 
 
+# per-source extra flags (tuning: DINODET_ATTN_NOSLP=1 builds the attention kernels without SLP vectorisation -- hipcc packs adjacent
+# fp32 adds / multiplies of the softmax into v_pk_*_f32, which issue slower beside MFMAs than the scalar forms)
+EXTRA = {}
+if os.environ.get("DINODET_ATTN_NOSLP") == "1":
+    EXTRA = {"attn_bf16.hip": ["-fno-slp-vectorize"], "attn_x3.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -44,10 +51,11 @@ def _compile(src):
     s = os.path.join(CSRC, src)
     o = os.path.join(OBJ, src.replace(".hip", ".o"))
     stamp = o + ".sha"
-    d = _digest([s] + HEADERS)
+    extra = EXTRA.get(src, [])
+    d = _digest([s] + HEADERS) + "|" + " ".join(extra)
     if os.path.exists(o) and os.path.exists(stamp) and open(stamp).read() == d:
         return o, False
-    cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+    cmd = [_hipcc()] + FLAGS + extra + ["-c", s, "-o", o]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
