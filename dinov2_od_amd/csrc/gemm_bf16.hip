@@ -770,7 +770,7 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   // one workgroup per CU nothing hides the GELU epilogue, so activations with a transcendental stay on the 2-workgroup kernel.
   // (also at small grids: at M = 10960 -- batch 8 -- QKV 730 vs 639, out-proj 396 vs 375, fc2 634 vs 526 TFLOP/s)
   if (force && force[0] == 'p' && K % 64 == 0) return launch_gemm_bf16_pp(A, lda, W, ldw, M, N, K, e, s);
-  if (force && force[0] == 'q' && K % 64 == 0) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
+  if (force && (force[0] == 'q' || force[0] == 'r') && K % 64 == 0) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
   if (force ? force[0] == 'x' : (M >= 4096 && N >= 512 && e.act != ACT_GELU && e.act != ACT_SIGMOID && e.rows_per_img == 0))
     return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
   // shape heuristic (measured on MI355X, tools/bench_gemm_k.py / bench_ops.py at M = 87680, random data):

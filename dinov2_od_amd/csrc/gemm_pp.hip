@@ -180,7 +180,10 @@ __global__ __launch_bounds__(512) void gemm_pp_256x256_kernel(const bf16_t* __re
 // Prefetch per K-tile u: LOAD 0 stages A-plane 0 of tile u+1, LOAD 1 A-plane 1 of u+1 (their buffer has been idle since tile
 // u-1), LOAD 2 / 3 the two W planes of tile u+2 (tile u's W planes are dead after every wave's LOAD 0); ONE counted wait per
 // K-tile, vmcnt(4) at the end of LOAD 3 (tile u+1 complete, the two W planes of u+2 still in flight).
-template <bool X3>
+// DC = true: the two LDS-DMA instructions of a phase are issued from inside the COMPUTE segment (between its MFMAs, whose issue slots
+// have slack: an MFMA holds the issue port for half its 16 cycles) instead of the LOAD segment, whose length -- not the MFMAs' --
+// paces the ping-pong once it exceeds the partner's COMPUTE; the counted wait of LOAD 3 then leaves vmcnt(2) (one plane) in flight.
+template <bool X3, bool DC>
 __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __restrict__ A, int lda,
                                                                const bf16_t* __restrict__ W, int ldw, int M, int N,
                                                                int K, GemmEpi e, int GM) {
@@ -211,18 +214,14 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
   char* const sdst = smem + wu * 2048;
   constexpr int KT = X3 ? 32 : 64;                 // k per K-tile
   const int pl1 = X3 ? K : 32;                      // element offset of an operand's second plane
-#define PPM_STAGE(t, pl)                                                                                       \
+#define PPM_STAGE_H(t, pl, hh)                                                                                 \
   {                                                                                                            \
-    char* d_ = sdst + ((t) & 1) * PP_TILE + (pl) * PP_PLANE;                                                   \
+    char* d_ = sdst + ((t) & 1) * PP_TILE + (pl) * PP_PLANE + (hh) * 1024;                                     \
     const int ko_ = ((t) * KT + (((pl) & 1) ? pl1 : 0)) * 2;                                                   \
-    if ((pl) < 2) {                                                                                            \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(d_), 16, vA0, ko_, 0, 0);                          \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(d_ + 1024), 16, vA1, ko_, 0, 0);                   \
-    } else {                                                                                                   \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(d_), 16, vW0, ko_, 0, 0);                          \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(d_ + 1024), 16, vW1, ko_, 0, 0);                   \
-    }                                                                                                          \
+    if ((pl) < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(d_), 16, (hh) ? vA1 : vA0, ko_, 0, 0); \
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(d_), 16, (hh) ? vW1 : vW0, ko_, 0, 0);          \
   }
+#define PPM_STAGE(t, pl) { PPM_STAGE_H(t, pl, 0) PPM_STAGE_H(t, pl, 1) }
   f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -256,8 +255,8 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
       a0[ii] = *reinterpret_cast<const bf16x8*>((st) + offA[2 * (q) + ii]);                                    \
       a1[ii] = *reinterpret_cast<const bf16x8*>((st) + offA[2 * (q) + ii] + PP_PLANE);                         \
     }                                                                                                          \
-    if (PF_ON) PPM_STAGE(PF_T, PF_PL)                                                                          \
-    if ((VW) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
+    if (!DC && (PF_ON)) PPM_STAGE(PF_T, PF_PL)                                                                 \
+    if ((VW) == 4) { if (DC) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
     else if ((VW) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
@@ -266,6 +265,11 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
     __builtin_amdgcn_s_setprio(1);                                                                             \
     _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                           \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+        if (DC && (PF_ON) && j == 1) {                                                                         \
+          __builtin_amdgcn_sched_barrier(0);                                                                   \
+          PPM_STAGE_H(PF_T, PF_PL, ii)                                                                         \
+          __builtin_amdgcn_sched_barrier(0);                                                                   \
+        }                                                                                                      \
         f32x4 c_ = acc[2 * (q) + ii][j];                                                                       \
         if (X3) {                                                                                              \
           c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], a0[ii], c_, 0, 0, 0);   /* Wl Ah: small terms first */ \
@@ -357,8 +361,10 @@ static void ppm_attr() {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
     attr_set[dev] = true;
   }
 }
@@ -372,7 +378,9 @@ int launch_gemm_bf16_ppm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int
   ppm_attr();
   const int gm = gemm_tile_mode();
   const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
-  hipLaunchKernelGGL(gemm_ppm_256x256_kernel<false>, dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
+  const char* f_ = getenv("DINODET_GEMM_TILE");
+  if (f_ && f_[0] == 'r') hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, true>), dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
+  else hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, false>), dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -389,6 +397,8 @@ int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int 
   if (getenv("DINODET_DEBUG_LDA0")) lda = 0;      // tuning only: every A row aliases row 0 (A traffic becomes cache hits)
   const int gm = gemm_tile_mode();
   const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
-  hipLaunchKernelGGL(gemm_ppm_256x256_kernel<true>, dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e2, gm);
+  const char* v_ = getenv("DINODET_X3_TILE");
+  if (v_ && v_[0] == 'p' && v_[1] == 'd') hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, true>), dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e2, gm);
+  else hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, false>), dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e2, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
