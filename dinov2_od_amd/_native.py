@@ -84,6 +84,8 @@ SYMBOLS = {
     "dod_op_split_pair": (_I, [_P, _I, _I, _I, _P, _P]),
     "dod_op_linear_x3": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "dod_op_attention_x3": (_I, [_P, _P, _I, _I, _I, _F, _P]),
+    "dod_op_split_h2": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "dod_op_linear_h2": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "dod_op_layernorm": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _I, _P]),
     "dod_op_attention_bf16": (_I, [_P, _P, _I, _I, _I, _F, _P]),
     "dod_op_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
@@ -105,6 +107,7 @@ SYMBOLS = {
     "dod_backbone_tail_train_forward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _P, _P, _SZ, _P, _SZ, _P]),
     "dod_backbone_tail_train_backward": (_I, [C.POINTER(DodConfig), _P, _I, _I, _P, _P, _SZ, _P, _P, _SZ, _P]),
     "dod_debug_gemm_stamps": (_I, [_P]),
+    "dod_debug_pp_stamps": (_I, [_P]),
     "dod_debug_attn_stamps": (_I, [_P]),
     "dod_debug_mfma_peak": (_I, [_I, _I, _I, _P, _P]),
     "dod_debug_mfma_valu_probe": (_I, [_I, _I, _I, _I, _P, _P]),

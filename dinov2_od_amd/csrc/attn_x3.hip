@@ -144,7 +144,7 @@ __device__ __forceinline__ void x3_tile(const char* st, const bf16x8 (&qh)[4], c
 }
 
 __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const bf16_t* __restrict__ qkv2, bf16_t* __restrict__ ctx3, int N,
-                                                         int heads, int npairs, float scale_log2e) {
+                                                         int heads, int npairs, float scale_log2e, int ctx_h2) {
   __shared__ __attribute__((aligned(16))) char smem[2 * X3_SLOT];   // 64 KiB
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -217,7 +217,22 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const bf16_t* __restric
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   const int q = q0 + lr;
-  if (active && q < N) {
+  if (active && q < N && ctx_h2) {       // H2 operand rows for the out-proj of the fp16x2 mode (dod_common.h)
+    char* row = reinterpret_cast<char*>(ctx3) + ((size_t)b * N + q) * 4 * D;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        uint2 f16; unsigned hi8, lo8;
+        h2_quad(v, 1.0f, f16, hi8, lo8);
+        const int c = h * 64 + db * 32 + 8 * g + 4 * lh;
+        *reinterpret_cast<uint2*>(row + 2 * c) = f16;
+        char* p8 = row + h2_off8(D, c);
+        *reinterpret_cast<unsigned*>(p8) = hi8;
+        *reinterpret_cast<unsigned*>(p8 + 16) = lo8;
+      }
+  } else if (active && q < N) {
     bf16_t* op = ctx3 + ((size_t)b * N + q) * 2 * D + h * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -237,11 +252,11 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const bf16_t* __restric
 }
 
 // qkv2 [B*N, 6*D] bf16 = [hi(q|k|v) | lo(q|k|v)]  ->  ctx3 [B*N, 2*D] bf16 = [hi | lo]
-int launch_attn_x3(const bf16_t* qkv2, bf16_t* ctx3, int B, int N, int heads, float scale, hipStream_t s) {
+int launch_attn_x3(const bf16_t* qkv2, bf16_t* ctx3, int B, int N, int heads, float scale, hipStream_t s, int ctx_h2) {
   if (B <= 0 || N <= 0 || heads <= 0) return 1;
   const int npairs = B * heads, pairs8 = (npairs + 7) / 8 * 8;
   const int nqb = (N + X3_WAVES * 32 - 1) / (X3_WAVES * 32);
   hipLaunchKernelGGL(attn_x3_kernel, dim3(pairs8 * nqb), dim3(256), 0, s, qkv2, ctx3, N, heads, npairs,
-                     scale * 1.44269504088896340736f);
+                     scale * 1.44269504088896340736f, ctx_h2);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -1037,6 +1037,23 @@ int dod_op_linear_x3(const void* A2, const void* W2, int M, int N, int K, const 
   if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear_x3 rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
   return DOD_OK;
 }
+int dod_op_split_h2(const float* x, int ld, int rows, int cols, void* out, void* wexp, void* stream) {
+  if (!x || !out) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  int r = launch_split_h2(x, ld, out, rows, cols, (unsigned char*)wexp, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_split_h2 rejected rows=%d cols=%d (rc %d)", rows, cols, r);
+  return DOD_OK;
+}
+int dod_op_linear_h2(const void* A, const void* W, const void* wexp, int M, int N, int K, const float* bias, const float* scale, const float* resid,
+                     int ldr, void* out, int out_layout, int ldc, int act, void* stream) {
+  if (!A || !W || !wexp || !out) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  GemmEpi e = epi(bias, out_layout == 0 ? (float*)out : nullptr, out_layout != 0 ? out : nullptr, ldc, act, scale, resid, ldr);
+  if (out_layout == 2) e.out_split = -N;       // bf16 pair layout [hi | lo]
+  if (out_layout == 3) e.out_h2 = 1;           // H2 operand rows
+  e.h2_wexp = (const unsigned char*)wexp;
+  int r = launch_gemm_h2(A, 4 * K, W, 3 * K, M, N, K, e, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear_h2 rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
+  return DOD_OK;
+}
 int dod_op_attention_x3(const void* qkv2, void* ctx2, int B, int N, int heads, float scale, void* stream) {
   if (!qkv2 || !ctx2) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
   int r = launch_attn_x3((const bf16_t*)qkv2, (bf16_t*)ctx2, B, N, heads, scale, (hipStream_t)stream);

@@ -41,6 +41,34 @@ __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d
   w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
   return (unsigned)w;
 }
+// ---- "H2" operand format (fp16 main product + e4m3 compensation terms; gemm_pp.hip gemm_h2_256x256_kernel, the fp16x2 precision mode)
+// x = h + l with h = fp16(x) (11 significant bits) and l = x - h (|l| <= 2^-11 |x|).  x.w ~ hx hw + [hx lw + lx hw]: the main product
+// on the fp16 MFMA, the two cross terms -- which only need ~4 significant bits to sit below 2^-16 of the result -- as ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 whose 64 k-slots per lane pair e4m3(hx) with e4m3(lw 2^(e+11)) and e4m3(lx 2^11) with
+// e4m3(hw 2^e): every product carries the same factor 2^(e+11), which the weight row's E8M0 block scale 2^-(e+11) removes before
+// the fp32 accumulation: 2.0 bf16-MFMA-equivalents per product instead of the 3 of the bf16 split form.
+//   activation row of K elements (K % 32 == 0), 4K bytes: [ fp16 x K | per 16-k group: 16 x e4m3(h), 16 x e4m3(l 2^11) ]
+//   weight row, 3K bytes + one exponent byte:             [ fp16 x K | K x e4m3(l 2^(e+11)) ],  e = floor(log2(448 / max|h|)) per row;
+//     e4m3(h 2^e) is derived from the fp16 fragments in the kernel (v_cvt_scalef32_pk_fp8_f16: 25 % fewer weight bytes through
+//     the per-CU global->LDS path, which -- not the MFMAs -- paces this kernel).  The activations keep their e4m3(h) bytes: that
+//     conversion turns |h| > 464 into NaN (no saturating form exists), so it needs the producer's clamp.
+// Values are clamped to the fp16 / e4m3 finite ranges (|x| <= 65504; beyond it the mode degrades, it does not overflow).
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ float clampf_(float v, float lim) { return __builtin_fminf(__builtin_fmaxf(v, -lim), lim); }
+// four values -> fp16 (2 dwords), e4m3 of the fp16 value times 2^ehi and of the remainder times 2^(ehi + 11) (one dword each)
+__device__ __forceinline__ void h2_quad(float4 v, float shi, uint2& f16, unsigned& hi8, unsigned& lo8) {
+  v.x = clampf_(v.x, 65504.f); v.y = clampf_(v.y, 65504.f); v.z = clampf_(v.z, 65504.f); v.w = clampf_(v.w, 65504.f);
+  const f16x2 p0 = {(_Float16)v.x, (_Float16)v.y}, p1 = {(_Float16)v.z, (_Float16)v.w};
+  f16.x = __builtin_bit_cast(unsigned, p0); f16.y = __builtin_bit_cast(unsigned, p1);
+  const float hx = (float)p0.x, hy = (float)p0.y, hz = (float)p1.x, hw = (float)p1.y;
+  const float slo = shi * 2048.0f;
+  hi8 = pack4_fp8(clampf_(hx * shi, 448.f), clampf_(hy * shi, 448.f), clampf_(hz * shi, 448.f), clampf_(hw * shi, 448.f));
+  lo8 = pack4_fp8(clampf_((v.x - hx) * slo, 448.f), clampf_((v.y - hy) * slo, 448.f), clampf_((v.z - hz) * slo, 448.f), clampf_((v.w - hw) * slo, 448.f));
+}
+// byte offset of the e4m3(h) bytes of column c (c % 4 == 0) inside an H2 activation row of K elements; the remainder bytes follow 16 bytes on
+__device__ __forceinline__ size_t h2_off8(int K, int c) { return (size_t)2 * K + (size_t)(c >> 4) * 32 + (c & 15); }
+
 // exact-erf GELU (HF ACT2FN["gelu"], modeling_dinov2.py:288-296)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16
@@ -82,6 +110,8 @@ struct GemmEpi {
                           // < 0 pair layout [hi | lo], each -out_split wide (ldc = -2*out_split)
   const float* a_scale;   // fp8 GEMM only: per-row (token) dequant scale of A, [M]; null otherwise
   const float* w_scale;   // fp8 GEMM only: per-output-feature dequant scale of W, [N]
+  int out_h2;             // with out_bf16: H2 activation rows (above) of N columns at row pitch ldc (2-byte units, >= 2N)
+  const unsigned char* h2_wexp;   // H2 GEMM only: E8M0 byte (127 - e) of every weight row's e4m3 scale 2^e, [N]
 };
 
 // ----------------------------------------------------------------------------- launchers (all enqueue on `s`, no sync)
@@ -96,7 +126,8 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
 // rows x cols fp32 or bf16 -> e4m3 with one scale per row: scale[r] = amax_r / 448 (1 if the row is all zero),
 // q = rne_e4m3(x / scale[r]).  in_bf16: input element type.  ld in elements.
 // bf16x3-mode attention: qkv2 [B*N, 6*D] = [hi(q|k|v) | lo(q|k|v)] -> ctx2 [B*N, 2*D] = [hi | lo]; head_dim 64
-int launch_attn_x3(const bf16_t* qkv2, bf16_t* ctx3, int B, int N, int heads, float scale, hipStream_t s);
+// ctx_h2: write the context in the H2 operand format (row pitch 4*D bytes) instead of the pair layout
+int launch_attn_x3(const bf16_t* qkv2, bf16_t* ctx3, int B, int N, int heads, float scale, hipStream_t s, int ctx_h2 = 0);
 // SwiGLU (silu(a) * b of the bf16 [rows, 2*Fh] input) -> e4m3 [rows, Fh] + per-row scale
 int launch_swiglu_fp8(const bf16_t* in, int rows, int Fh, unsigned char* q, float* scale, hipStream_t s);
 int launch_quant_rows_fp8(const void* x, int in_bf16, int ld, int rows, int cols, unsigned char* q, int ldq, float* scale,
@@ -105,9 +136,10 @@ int launch_quant_rows_fp8(const void* x, int in_bf16, int ld, int rows, int cols
 // rows x D LayerNorm, optional pre-add (y = LN(x + add)), fp32 statistics; out bf16 or fp32
 // out_fp8 / out_scale (both or neither): e4m3 row + per-row scale (amax / 448) instead of the fp32 / bf16 output;
 // out_split3: split-product pair layout [hi | lo] (row pitch 2*D) instead
+// h2: out_split3 is written in the H2 operand format (row pitch 4*D bytes) instead
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s,
-                     unsigned char* out_fp8 = nullptr, float* out_scale = nullptr, bf16_t* out_split3 = nullptr);
+                     unsigned char* out_fp8 = nullptr, float* out_scale = nullptr, bf16_t* out_split3 = nullptr, int h2 = 0);
 
 // backbone attention, bf16 MFMA flash kernel, head_dim 64.  qkv [B*N, 3*D] bf16 -> ctx [B*N, D] bf16
 int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s);
@@ -143,6 +175,11 @@ int launch_lora_merge(const float* W, const float* A, const float* Bm, float alp
 // bf16x3 split: fp32 [rows,K] -> bf16 [rows,3K]; mode 0 = [hi|hi|lo] (activations), 1 = [hi|lo|hi] (weights)
 int launch_split3(const float* in, int ld_in, bf16_t* out, int rows, int K, int mode, hipStream_t s);
 int launch_split2(const float* in, int ld_in, bf16_t* out, int rows, int K, hipStream_t s);   // [hi | lo], pitch 2K
+// fp32 [rows, K] -> H2 operand rows.  wexp == null: activation form (4K bytes per row); else the weight form (3K bytes per row,
+// wexp[row] = 127 - e)
+int launch_split_h2(const float* in, int ld_in, void* out, int rows, int K, unsigned char* wexp, hipStream_t s);
+// H2 GEMM (gemm_pp.hip): A [M, K] activation rows (pitch lda BYTES >= 4K), W [N, K] weight rows (pitch ldw BYTES >= 3K), e.h2_wexp set
+int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 // split-product GEMM on pair-layout operands A2 [M, 2K], W2 [N, 2K] (gemm_x3.hip)
 int launch_gemm_bf16_k64(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 int gemm_tile_mode();   // tile-order mode word of the 256-row kernels (gemm_x3.hip; gemm_epi.h tile_map)

@@ -12,7 +12,20 @@ __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row 
 // Chunked map: the tile list is cut into chunks of 8 groups; group k of a chunk runs on XCD k, chunks run one after the other, so
 // the whole chip moves through M together -- in the order the producer kernel wrote the A rows (or, with the reverse bit, most
 // recently written rows first: those are the ones still in the 256-MiB Infinity Cache).  Both maps are bijections for any grid.
+// Start stagger (mode bits 16..27 = delay step in units of 0.16 us, bits 12..15 = groups - 1): the workgroups of the first round
+// (one per CU) in group k = (b / 8) % groups start k steps late, so that the CUs' HBM-bound epilogues -- which otherwise all run at
+// the same instants, between compute-only K loops -- interleave with the other groups' K loops.
+__device__ __forceinline__ void stagger_start(int b, int mode) {
+  const int sd = (mode >> 16) & 0xfff;
+  if (sd == 0 || b >= 256) return;
+  const int k = (b >> 3) % (((mode >> 12) & 0xf) + 1);
+  if (k == 0) return;
+  const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)k * sd * 16;
+  while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
+}
+
 __device__ __forceinline__ void tile_map(int b, int tiles_m, int tiles_n, int mode, int* tm_out, int* tn_out) {
+  stagger_start(b, mode);
   const int GM = mode & 0xff;
   const int nwg = tiles_m * tiles_n;
   int tm, tn;
@@ -112,6 +125,14 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
     }
     if (e.out_f32) {
       *reinterpret_cast<float4*>(e.out_f32 + orow * e.ldc + n) = v;
+    } else if (e.out_h2) {          // H2 operand row of the next GEMM (dod_common.h)
+      uint2 f16; unsigned hi8, lo8;
+      h2_quad(v, 1.0f, f16, hi8, lo8);
+      char* row = reinterpret_cast<char*>(e.out_bf16) + orow * (size_t)e.ldc * 2;
+      *reinterpret_cast<uint2*>(row + 2 * n) = f16;
+      char* p8 = row + h2_off8(N, n);
+      *reinterpret_cast<unsigned*>(p8) = hi8;
+      *reinterpret_cast<unsigned*>(p8 + 16) = lo8;
     } else if (e.out_split > 0) {   // bf16x3 activation operand of the next GEMM: [hi | hi | lo]
       uint2 hi, lo;
       hi.x = pack2bf(v.x, v.y);
@@ -175,6 +196,17 @@ __device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, con
     }
     v.x *= s0.x; v.y *= s0.y; v.z *= s0.z; v.w *= s0.w;
     u.x *= s1.x; u.y *= s1.y; u.z *= s1.z; u.w *= s1.w;
+    if (e.out_h2) {                 // H2 operand row of the next GEMM (dod_common.h): 16 B of fp16, 8 + 8 B of e4m3
+      uint2 fa, fb; unsigned h0, l0, h1, l1;
+      h2_quad(v, 1.0f, fa, h0, l0);
+      h2_quad(u, 1.0f, fb, h1, l1);
+      char* row = reinterpret_cast<char*>(e.out_bf16) + (size_t)m * e.ldc * 2;
+      *reinterpret_cast<uint4*>(row + 2 * n) = make_uint4(fa.x, fa.y, fb.x, fb.y);
+      char* p8 = row + h2_off8(N, n);
+      *reinterpret_cast<uint2*>(p8) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(p8 + 16) = make_uint2(l0, l1);
+      continue;
+    }
     uint4 hi;
     hi.x = pack2bf(v.x, v.y); hi.y = pack2bf(v.z, v.w); hi.z = pack2bf(u.x, u.y); hi.w = pack2bf(u.z, u.w);
     bf16_t* o = e.out_bf16 + (size_t)m * e.ldc + n;

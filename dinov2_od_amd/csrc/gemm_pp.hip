@@ -180,6 +180,14 @@ __global__ __launch_bounds__(512) void gemm_pp_256x256_kernel(const bf16_t* __re
 // Prefetch per K-tile u: LOAD 0 stages A-plane 0 of tile u+1, LOAD 1 A-plane 1 of u+1 (their buffer has been idle since tile
 // u-1), LOAD 2 / 3 the two W planes of tile u+2 (tile u's W planes are dead after every wave's LOAD 0); ONE counted wait per
 // K-tile, vmcnt(4) at the end of LOAD 3 (tile u+1 complete, the two W planes of u+2 still in flight).
+// tuning only (tools/pp_timeline.py): when non-null, lane 0 of wave 0 of every workgroup stores {s_memtime at entry, after the prologue,
+// after the K loop, at exit (stores drained), s_memrealtime at entry, at exit, blockIdx, 0}
+__device__ unsigned long long* g_pp_stamps = nullptr;
+extern "C" int dod_debug_pp_stamps(void* dev_buf) {
+  unsigned long long* p = (unsigned long long*)dev_buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_pp_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 3;
+}
+
 // DC = true: the two LDS-DMA instructions of a phase are issued from inside the COMPUTE segment (between its MFMAs, whose issue slots
 // have slack: an MFMA holds the issue port for half its 16 cycles) instead of the LOAD segment, whose length -- not the MFMAs' --
 // paces the ping-pong once it exceeds the partner's COMPUTE; the counted wait of LOAD 3 then leaves vmcnt(2) (one plane) in flight.
@@ -192,6 +200,9 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
   const int wu = __builtin_amdgcn_readfirstlane(wid);
   const int grp_ = wu >> 2, wq = wu & 3;
   const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
+  unsigned long long* const stamps = g_pp_stamps;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tr0 = 0;
+  if (stamps) { ts0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
   int tm, tn;
   tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
   const int m0 = tm * PPM, n0 = tn * PPN;
@@ -242,6 +253,7 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
   if (grp_ == 1) __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
+  if (stamps) ts1 = __builtin_amdgcn_s_memtime();
   bf16x8 w0[4], w1[4], a0[2], a1[2];       // plane-0 / plane-1 fragments
 #define PPM_PHASE(st, q, PF_ON, PF_T, PF_PL, VW)                                                               \
   {                                                                                                            \
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
   }
   if (grp_ == 0) __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if (stamps) ts2 = __builtin_amdgcn_s_memtime();
 
   constexpr int PITCH = PPN * 4 + 16;
   const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
@@ -332,6 +345,245 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
     if (wide) drain_tile_bf16x8<128, PPN, 512>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
     else drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid,
                                    [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+  }
+  if (stamps && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* o = stamps + (size_t)blockIdx.x * 8;
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime(); o[4] = tr0; o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = blockIdx.x; o[7] = 0;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// H2 GEMM (the fp16x2 precision mode): the ping-pong structure above on H2-format operands (dod_common.h) --
+// x.w ~ fp16(x) fp16(w) on v_mfma_f32_32x32x16_f16 plus BOTH cross terms as one block-scaled e4m3 MFMA
+// (v_mfma_scale_f32_32x32x64_f8f6f4; per lane the k-slots [e4m3(hx) | e4m3(lx 2^11)] . [e4m3(lw 2^(e+11)) | e4m3(hw 2^e)]).
+//   * planes of a 32-k K-tile: A fp16 | A e4m3 (main, remainder) | W fp16, each [256 rows][64 B], and W e4m3 remainder
+//     [256 rows][32 B]: 56 KiB per K-tile, two buffers;
+//   * 32x32 MFMA lane map: lane (r = lane & 31, g = lane >> 5) reads the 32 bytes (chunks 2g, 2g+1) of row r of a 64-byte plane:
+//     fp16 k 16g..16g+15 (two 32x32x16 products: any k order both operands share is a valid dot product), or the e4m3 main and
+//     remainder bytes of the same 16 k; from the 32-byte plane chunk g.  chunk ^= (row >> 2) & 3 (64-byte rows) and
+//     chunk ^= (row >> 3) & 1 (32-byte rows) make every ds_read_b128 lane group conflict-free;
+//   * e4m3(hw 2^e) is converted from the fp16 weight fragments once per K-tile (8 v_cvt_scalef32_pk_fp8_f16 per 32 x 16 block,
+//     which divides by its scale operand: 2^-e, built from the row's exponent byte);
+//   * TWO phases per K-tile (row blocks 2p, 2p+1 of the wave's four): 12 MFMAs = 4 * 64 + 8 * 32 = 512 matrix-pipe cycles per
+//     COMPUTE segment; per 32x32 block and K-tile 128 cycles against 192 for the three bf16 products;
+//   * E8M0 scale operands: weights 2^-(e_n + 11) (one byte per n-block, constant over K), activations 2^0.
+// Rings: THREE A buffers (2 x 16 KiB planes each), TWO W buffers (16 + 8 KiB): 144 KiB.  The A panel streams from beyond L2 (every
+// m-tile's rows are fetched by only tiles_n workgroups), so its planes are staged TWO K-tiles ahead; the W planes, shared by every
+// m-tile of the XCD's group and L2 / Infinity-Cache resident, one and a half.  Per K-tile u: LOAD 0 stages the A planes of tile
+// u + 2 (4 pieces), LOAD 1 the W planes of tile u + 2 (3 pieces); one counted wait per K-tile, vmcnt(7) at the end of LOAD 1 (tile
+// u + 1 complete, tile u + 2 in flight).  With A one K-tile ahead (half a K-tile of flight) the loop ran at 2600 cycles per K-tile
+// against 2048 of MFMA work -- and at 2130 with every A row aliased to one row (cache hits): it waited for the A panel.
+__device__ __forceinline__ int h2_swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+typedef __attribute__((ext_vector_type(8))) int i32x8_;
+typedef __attribute__((ext_vector_type(4))) int i32x4_;
+typedef __attribute__((ext_vector_type(2))) short s16x2_;
+#define H2_ABUF (32 * 1024)        // A buffer t % 3: fp16 plane, then the e4m3 (main, remainder) plane
+#define H2_A8 (16 * 1024)
+#define H2_WBASE (3 * H2_ABUF)     // W buffer t & 1: fp16 plane (16 KiB), then the e4m3 remainder plane (8 KiB)
+#define H2_WBUF (24 * 1024)
+#define H2_WL (16 * 1024)
+#define H2_LDS (H2_WBASE + 2 * H2_WBUF)
+
+// 8 fp16 (one 16-byte fragment) -> 8 e4m3 bytes of (value / inv_scale), round to nearest even
+__device__ __forceinline__ void h2_cvt8(const bf16x8& raw, float inv_scale, int& d0, int& d1) {
+  const f16x8 v = __builtin_bit_cast(f16x8, raw);
+  s16x2_ r0 = {0, 0}, r1 = {0, 0};
+  r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, f16x2{v[0], v[1]}, inv_scale, false);
+  r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, f16x2{v[2], v[3]}, inv_scale, true);
+  r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, f16x2{v[4], v[5]}, inv_scale, false);
+  r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, f16x2{v[6], v[7]}, inv_scale, true);
+  d0 = __builtin_bit_cast(int, r0); d1 = __builtin_bit_cast(int, r1);
+}
+
+__global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __restrict__ A, int lda, const char* __restrict__ W, int ldw,
+                                                              int M, int N, int K, GemmEpi e, int GM) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const int grp_ = wu >> 2, wq = wu & 3;
+  const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
+  unsigned long long* const stamps = g_pp_stamps;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tr0 = 0;
+  if (stamps) { ts0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
+  int tm, tn;
+  tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
+  const int m0 = tm * PPM, n0 = tn * PPN;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // staging (buffer-descriptor LDS-DMA): 64-byte planes as two 16-row pieces per wave (lane -> row = lane >> 2, LDS chunk slot
+  // lane & 3, fetching global chunk slot ^ swizzle(row)); the 32-byte W remainder plane as ONE 32-row piece (row = lane >> 1)
+  unsigned vA0, vA1, vW0, vW1, vWl;
+  {
+    const int rl = wid * 32 + (lane >> 2);
+    const int c = h2_swz(rl, lane & 3);              // rows rl and rl + 16 share (row >> 2) & 3
+    int ra0 = m0 + rl, ra1 = m0 + rl + 16; ra0 = ra0 < M ? ra0 : M - 1; ra1 = ra1 < M ? ra1 : M - 1;
+    int rw0 = n0 + rl, rw1 = n0 + rl + 16; rw0 = rw0 < N ? rw0 : N - 1; rw1 = rw1 < N ? rw1 : N - 1;
+    vA0 = (unsigned)((size_t)ra0 * lda + c * 16); vA1 = (unsigned)((size_t)ra1 * lda + c * 16);
+    vW0 = (unsigned)((size_t)rw0 * ldw + c * 16); vW1 = (unsigned)((size_t)rw1 * ldw + c * 16);
+    const int r2 = wid * 32 + (lane >> 1);
+    int rwl = n0 + r2; rwl = rwl < N ? rwl : N - 1;
+    vWl = (unsigned)((size_t)rwl * ldw + 2 * (size_t)K + (((lane & 1) ^ ((r2 >> 3) & 1)) * 16));
+  }
+  const size_t bytesA = (size_t)M * lda, bytesW = (size_t)N * ldw;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(bytesA > 0xfffffff0u ? 0xfffffff0u : bytesA), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)(bytesW > 0xfffffff0u ? 0xfffffff0u : bytesW), 0x00020000);
+  const int K2 = 2 * K;
+  // A planes of K-tile t into A buffer ab (4 pieces per wave); W planes of K-tile t into W buffer t & 1 (3 pieces)
+#define H2_STAGE_A(t, ab)                                                                                      \
+  {                                                                                                            \
+    char* b_ = smem + (ab) * H2_ABUF + wu * 2048;                                                              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_), 16, vA0, (t) * 64, 0, 0);                       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_ + 1024), 16, vA1, (t) * 64, 0, 0);                \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_ + H2_A8), 16, vA0, K2 + (t) * 64, 0, 0);          \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_ + H2_A8 + 1024), 16, vA1, K2 + (t) * 64, 0, 0);   \
+  }
+#define H2_STAGE_W(t)                                                                                          \
+  {                                                                                                            \
+    char* b_ = smem + H2_WBASE + ((t) & 1) * H2_WBUF;                                                          \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(b_ + wu * 2048), 16, vW0, (t) * 64, 0, 0);           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(b_ + wu * 2048 + 1024), 16, vW1, (t) * 64, 0, 0);    \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(b_ + H2_WL + wu * 1024), 16, vWl, (t) * 32, 0, 0);   \
+  }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = K / 32;
+  const int lr = lane & 31, lg = lane >> 5;
+  int offA[4], offW[2], offWl[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int row = grp_ * 128 + i * 32 + lr; offA[i] = row * 64 + h2_swz(row, 2 * lg) * 16; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wq * 64 + j * 32 + lr;
+    offW[j] = row * 64 + h2_swz(row, 2 * lg) * 16;
+    offWl[j] = H2_WL + row * 32 + ((lg ^ ((row >> 3) & 1)) * 16);
+  }
+  // E8M0 block scale of the weight operand (the two n-blocks' bytes in bits 0..7 / 8..15): 2^-(e + 11); and 2^-e as the divisor of
+  // the in-kernel fp16 -> e4m3 conversion (a float whose exponent field is the row's byte 127 - e)
+  int sc_w; float cinv[2];
+  {
+    int na = n0 + wq * 64 + lr, nb = na + 32;
+    na = na < N ? na : N - 1; nb = nb < N ? nb : N - 1;
+    const int ba = (int)e.h2_wexp[na], bb = (int)e.h2_wexp[nb];
+    cinv[0] = __uint_as_float((unsigned)ba << 23); cinv[1] = __uint_as_float((unsigned)bb << 23);
+    sc_w = (ba - 11 < 0 ? 0 : ba - 11) | ((bb - 11 < 0 ? 0 : bb - 11) << 8);
+  }
+  const int sc_a = 127;
+
+  H2_STAGE_A(0, 0) H2_STAGE_W(0)
+  if (nk > 1) { H2_STAGE_A(1, 1) H2_STAGE_W(1) }
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp_ == 1) __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (stamps) ts1 = __builtin_amdgcn_s_memtime();
+
+  bf16x8 w16[2][2], wl[2], a16[2][2], a8[2][2];      // read as ushort vectors (an int-typed read would make hipcc drain the DMA ring)
+  i32x8_ w8v[2];
+  // one phase: sa / sw = this K-tile's A / W buffers; PF: 0 nothing to stage, 1 the A planes of K-tile PF_T into A buffer PF_AB, 2 the W
+  // planes of K-tile PF_T; VW: vmcnt to wait for at the end of the LOAD segment (-1: none)
+#define H2_PHASE(sa, sw, p, PF, PF_T, PF_AB, VW)                                                               \
+  {                                                                                                            \
+    if ((p) == 0) {                                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+        w16[j][0] = *reinterpret_cast<const bf16x8*>((sw) + offW[j]);                                          \
+        w16[j][1] = *reinterpret_cast<const bf16x8*>((sw) + (offW[j] ^ 16));                                   \
+        wl[j] = *reinterpret_cast<const bf16x8*>((sw) + offWl[j]);                                             \
+      }                                                                                                        \
+    }                                                                                                          \
+    _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                         \
+      a16[ii][0] = *reinterpret_cast<const bf16x8*>((sa) + offA[2 * (p) + ii]);                                \
+      a16[ii][1] = *reinterpret_cast<const bf16x8*>((sa) + (offA[2 * (p) + ii] ^ 16));                         \
+      a8[ii][0] = *reinterpret_cast<const bf16x8*>((sa) + offA[2 * (p) + ii] + H2_A8);                         \
+      a8[ii][1] = *reinterpret_cast<const bf16x8*>((sa) + (offA[2 * (p) + ii] ^ 16) + H2_A8);                  \
+    }                                                                                                          \
+    if ((PF) == 1) H2_STAGE_A(PF_T, PF_AB)                                                                     \
+    if ((PF) == 2) H2_STAGE_W(PF_T)                                                                            \
+    if ((VW) == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                            \
+    else if ((VW) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                           \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+        f32x16 c_ = acc[2 * (p) + ii][j];                                                                      \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w16[j][0]), __builtin_bit_cast(f16x8, a16[ii][0]), c_, 0, 0, 0); \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w16[j][1]), __builtin_bit_cast(f16x8, a16[ii][1]), c_, 0, 0, 0); \
+        acc[2 * (p) + ii][j] = c_;                                                                             \
+      }                                                                                                        \
+    if ((p) == 0) {       /* e4m3(hw 2^e) from the fp16 weight fragments: under the main-product MFMAs above */  \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+        int d0, d1, d2, d3;                                                                                    \
+        h2_cvt8(w16[j][0], cinv[j], d0, d1);                                                                   \
+        h2_cvt8(w16[j][1], cinv[j], d2, d3);                                                                   \
+        const i32x4_ l_ = __builtin_bit_cast(i32x4_, wl[j]);                                                   \
+        w8v[j] = i32x8_{l_[0], l_[1], l_[2], l_[3], d0, d1, d2, d3};                                           \
+      }                                                                                                        \
+    }                                                                                                          \
+    _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                         \
+      const i32x8_ a8v = __builtin_shufflevector(__builtin_bit_cast(i32x4_, a8[ii][0]), __builtin_bit_cast(i32x4_, a8[ii][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
+      acc[2 * (p) + ii][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8v[0], a8v, acc[2 * (p) + ii][0], 0, 0, 0, sc_w, 0, sc_a); \
+      acc[2 * (p) + ii][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8v[1], a8v, acc[2 * (p) + ii][1], 0, 0, 1, sc_w, 0, sc_a); \
+    }                                                                                                          \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  }
+
+  int u = 0, ua = 0;                            // ua = u % 3
+  for (; u + 2 < nk; ++u) {
+    const char* sa = smem + ua * H2_ABUF;
+    const char* sw = smem + H2_WBASE + (u & 1) * H2_WBUF;
+    const int ab2 = ua == 0 ? 2 : ua - 1;       // (u + 2) % 3
+    H2_PHASE(sa, sw, 0, 1, u + 2, ab2, -1)
+    H2_PHASE(sa, sw, 1, 2, u + 2, 0, 7)
+    ua = ua == 2 ? 0 : ua + 1;
+  }
+  if (u + 1 < nk) {
+    const char* sa = smem + ua * H2_ABUF;
+    const char* sw = smem + H2_WBASE + (u & 1) * H2_WBUF;
+    H2_PHASE(sa, sw, 0, 0, 0, 0, -1)
+    H2_PHASE(sa, sw, 1, 0, 0, 0, 0)
+    ua = ua == 2 ? 0 : ua + 1;
+    ++u;
+  }
+  {
+    const char* sa = smem + ua * H2_ABUF;
+    const char* sw = smem + H2_WBASE + (u & 1) * H2_WBUF;
+    H2_PHASE(sa, sw, 0, 0, 0, 0, -1)
+    H2_PHASE(sa, sw, 1, 0, 0, 0, -1)
+  }
+  if (grp_ == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (stamps) ts2 = __builtin_amdgcn_s_memtime();
+
+  constexpr int PITCH = PPN * 4 + 16;
+  const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
+  const bool wide = drain8_ok(e, N);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) stage_acc(smem, PITCH, grp_ * 64 + ii * 32 + lr, wq * 64 + j * 32, acc[pass * 2 + ii][j], lg);
+    __syncthreads();
+    if (wide) drain_tile_bf16x8<128, PPN, 512>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+    else drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid,
+                                   [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+  }
+  if (stamps && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* o = stamps + (size_t)blockIdx.x * 8;
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime(); o[4] = tr0; o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = blockIdx.x; o[7] = 0;
   }
 }
 
@@ -400,5 +652,28 @@ int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int 
   const char* v_ = getenv("DINODET_X3_TILE");
   if (v_ && v_[0] == 'p' && v_[1] == 'd') hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, true>), dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e2, gm);
   else hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, false>), dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e2, gm);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// H2 operands (dod_common.h): A [M, K] activation rows at pitch lda bytes (>= 4K), W [N, K] weight rows at pitch ldw bytes (>= 3K)
+int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0) return 1;
+  if (K % 32 != 0 || N % 4 != 0 || lda % 16 != 0 || ldw % 16 != 0 || lda < 4 * K || ldw < 3 * K || !e.h2_wexp) return 2;
+  if (e.out_f32 && e.ldc % 4 != 0) return 2;
+  if (e.resid && e.ldr % 4 != 0) return 2;
+  if (!e.out_f32 && !e.out_bf16) return 2;
+  if (e.out_h2 && (N % 32 != 0 || e.ldc < 2 * N || e.ldc % 8 != 0 || e.out_split != 0)) return 2;
+  constexpr int LDSH2 = (128 * (PPN * 4 + 16)) > H2_LDS ? (128 * (PPN * 4 + 16)) : H2_LDS;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSH2);
+    attr_set[dev] = true;
+  }
+  const int gm = gemm_tile_mode();
+  const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
+  if (getenv("DINODET_DEBUG_LDA0")) lda = 0;      // tuning only: every A row aliases row 0 (A traffic becomes cache hits)
+  hipLaunchKernelGGL(gemm_h2_256x256_kernel, dim3(tiles), dim3(512), LDSH2, s, (const char*)A, lda, (const char*)W, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

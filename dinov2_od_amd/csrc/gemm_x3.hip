@@ -13,6 +13,7 @@
 // epilogue (gemm_epi.h), XCD-aware grouped tile order.
 #include "dod_common.h"
 #include "gemm_epi.h"
+#include <cstdio>
 #include <cstdlib>
 
 #define X3M 256
@@ -139,7 +140,15 @@ int gemm_tile_mode() {
   int gm = g ? atoi(g) : 4;
   if (gm < 1 || gm > 64) gm = 4;
   const int ord = o ? atoi(o) : 2;        // default: time-ordered map (measured +5 % on QKV / fc2, +3-5 % on out-proj at M = 87680)
-  return gm | ((ord & 1) ? 0x100 : 0) | ((ord & 2) ? 0x200 : 0);
+  int st = 0;
+  if (const char* sg = getenv("DINODET_GEMM_STAGGER")) {     // "groups,step_us" (tuning switch)
+    int G = 0; float us = 0.f;
+    if (sscanf(sg, "%d,%f", &G, &us) == 2 && G >= 2 && G <= 16 && us > 0.f) {
+      int step = (int)(us / 0.16f + 0.5f); step = step < 1 ? 1 : (step > 0xfff ? 0xfff : step);
+      st = ((G - 1) << 12) | (step << 16);
+    }
+  }
+  return gm | ((ord & 1) ? 0x100 : 0) | ((ord & 2) ? 0x200 : 0) | st;
 }
 
 static constexpr int LDSX3 = (128 * (X3N * 4 + 16)) > X3_SLOTS * X3_STAGE ? (128 * (X3N * 4 + 16)) : X3_SLOTS * X3_STAGE;

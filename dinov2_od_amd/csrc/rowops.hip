@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, int rows, int D, float* __restrict__ out_f32,
                                                         bf16_t* __restrict__ out_bf16, unsigned char* __restrict__ out_fp8,
-                                                        float* __restrict__ out_scale, bf16_t* __restrict__ out_split3) {
+                                                        float* __restrict__ out_scale, bf16_t* __restrict__ out_split3, int h2) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -80,7 +80,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
       if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[c] = o;
-      if (out_split3) {   // split-product operand in the pair layout [hi | lo] (row pitch 2*D)
+      if (out_split3 && h2) {   // H2 operand row (fp16 | e4m3 main, e4m3 remainder per 32-k block; dod_common.h)
+        uint2 f16; unsigned hi8, lo8;
+        h2_quad(o, 1.0f, f16, hi8, lo8);
+        char* ob = reinterpret_cast<char*>(out_split3) + (size_t)row * 4 * D;
+        reinterpret_cast<uint2*>(ob)[c] = f16;
+        char* p8 = ob + h2_off8(D, 4 * c);
+        *reinterpret_cast<unsigned*>(p8) = hi8;
+        *reinterpret_cast<unsigned*>(p8 + 16) = lo8;
+      } else if (out_split3) {   // split-product operand in the pair layout [hi | lo] (row pitch 2*D)
         uint2 hi, lo;
         hi.x = pack2bf(o.x, o.y);
         hi.y = pack2bf(o.z, o.w);
@@ -102,12 +110,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s, unsigned char* out_fp8,
-                     float* out_scale, bf16_t* out_split3) {
+                     float* out_scale, bf16_t* out_split3, int h2) {
   if (rows <= 0) return 1;
   if (D % 4 != 0 || D > 256 * LN_MAXC) return 2;
+  if (h2 && (!out_split3 || D % 32 != 0)) return 2;
   if ((out_fp8 == nullptr) != (out_scale == nullptr)) return 2;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, add, gamma, beta, eps, rows, D,
-                     out_f32, out_bf16, out_fp8, out_scale, out_split3);
+                     out_f32, out_bf16, out_fp8, out_scale, out_split3, h2);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -320,6 +329,49 @@ int launch_split2(const float* in, int ld_in, bf16_t* out, int rows, int K, hipS
   hipLaunchKernelGGL(split2_kernel, dim3(blocks), dim3(256), 0, s, in, ld_in, out, rows, K);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
+// fp32 [rows, K] -> H2 operand rows (dod_common.h).  One wave per row.  Weight form (wexp != null): the row's e4m3 scale 2^e is the
+// power of two that brings max|fp16(w)| into (224, 448]; only the remainder bytes are stored (3K-byte rows).
+__global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ in, int ld_in, char* __restrict__ out, int rows, int K,
+                                                       unsigned char* __restrict__ wexp) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = in + (size_t)row * ld_in;
+  float shi = 1.0f;
+  if (wexp) {
+    float amax = 0.f;
+    for (int c = lane; c < K; c += 64) amax = fmaxf(amax, fabsf((float)(_Float16)clampf_(xr[c], 65504.f)));
+    amax = wave_max(amax);
+    int e = 0;
+    if (amax > 0.f) {
+      int ex; const float m = frexpf(amax, &ex);           // amax = m 2^ex, m in [0.5, 1): amax 2^e <= 448 = 0.875 * 2^9
+      e = (m <= 0.875f ? 9 : 8) - ex;
+      e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    }
+    shi = ldexpf(1.0f, e);
+    if (lane == 0) wexp[row] = (unsigned char)(127 - e);
+  }
+  char* ob = out + (size_t)row * (wexp ? 3 : 4) * K;
+  for (int c = lane * 4; c < K; c += 256) {
+    const float4 v = make_float4(xr[c], xr[c + 1], xr[c + 2], xr[c + 3]);
+    uint2 f16; unsigned hi8, lo8;
+    h2_quad(v, shi, f16, hi8, lo8);
+    *reinterpret_cast<uint2*>(ob + 2 * c) = f16;
+    if (wexp) *reinterpret_cast<unsigned*>(ob + 2 * K + c) = lo8;
+    else {
+      char* p8 = ob + h2_off8(K, c);
+      *reinterpret_cast<unsigned*>(p8) = hi8;
+      *reinterpret_cast<unsigned*>(p8 + 16) = lo8;
+    }
+  }
+}
+int launch_split_h2(const float* in, int ld_in, void* out, int rows, int K, unsigned char* wexp, hipStream_t s) {
+  if (rows <= 0) return 1;
+  if (K % 32 != 0) return 2;
+  hipLaunchKernelGGL(split_h2_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in, ld_in, (char*)out, rows, K, wexp);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 int launch_split3(const float* in, int ld_in, bf16_t* out, int rows, int K, int mode, hipStream_t s) {
   const size_t total = (size_t)rows * K;
   if (total == 0) return 0;

@@ -169,6 +169,15 @@ int dod_op_split_pair(const float* x, int ld, int rows, int cols, void* out, voi
 int dod_op_linear_x3(const void* A2, const void* W2, int M, int N, int K, const float* bias, const float* scale,
                      const float* resid, int ldr, void* out, int out_layout, int ldc, int act, void* stream);
 int dod_op_attention_x3(const void* qkv2, void* ctx2, int B, int N, int heads, float scale, void* stream);
+/* fp16x2 (parity-gated mode) operators.  H2 operand format of a [rows, cols] matrix (cols % 32 == 0), 4*cols bytes per row:
+ *   [ fp16(x) x cols | per 32-column block: 32 x e4m3(h 2^e), 32 x e4m3((x - h) 2^(e+11)) ],  h = fp16(x);
+ *   activations: e = 0; weights (wexp != NULL): per row e = floor(log2(448 / max|h|)), wexp[row] = 127 - e (E8M0 byte) and the
+ *   two 32-byte halves of a block swapped, so that k-slot by k-slot main meets remainder.
+ * dod_op_linear_h2: act(A W^T + bias) * scale + resid with A W^T ~ fp16(A) fp16(W)^T + the two cross terms on block-scaled e4m3
+ *   MFMA operands; out_layout 0: fp32, 1: bf16, 2: bf16 pair layout [M, 2N], 3: H2 rows (ldc in 2-byte units, >= 2N). */
+int dod_op_split_h2(const float* x, int ld, int rows, int cols, void* out, void* wexp, void* stream);
+int dod_op_linear_h2(const void* A, const void* W, const void* wexp, int M, int N, int K, const float* bias, const float* scale,
+                     const float* resid, int ldr, void* out, int out_layout, int ldc, int act, void* stream);
 /* out = LayerNorm(x + add) ; add may be NULL */
 int dod_op_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, void* out, int out_dtype, void* stream);
@@ -295,6 +304,8 @@ int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_pa
  * {realtime at start, after the K loop, at exit, blockIdx} (100 MHz s_memrealtime); NULL switches it off.
  * Used by tools/gemm_timeline.py. */
 int dod_debug_gemm_stamps(void* dev_buf);
+/* same for the ping-pong kernels (gemm_pp.hip): 8 x uint64 per workgroup, shader cycles (tools/pp_timeline.py) */
+int dod_debug_pp_stamps(void* dev_buf);
 /* same for the bf16 attention kernel: {shader cycles in the tile loop, cycles waiting for DMA + barrier, tiles, active} */
 int dod_debug_attn_stamps(void* dev_buf);
 /* register-only MFMA loop (shape 16: v_mfma_f32_16x16x32_bf16 x 8 chains, 32: 32x32x16 x 4 chains, 2: v_mfma_f32_32x32x2_f32 x 4 chains, 1: the same as one dependent chain; iters < 0: random operands), `blocks` workgroups of

@@ -14,6 +14,10 @@ from dinov2_od_amd import _native as nat
 
 
 def set_variant(v):
+    os.environ.pop("DINODET_GEMM_STAGGER", None)
+    if "@" in v:                               # "<tile>@<groups>,<step_us>": start stagger
+        v, st = v.split("@")
+        os.environ["DINODET_GEMM_STAGGER"] = st
     if v.startswith("o"):                      # tile-order A/B: "o0".."o3"
         os.environ["DINODET_GEMM_ORDER"] = v[1:]
         return
@@ -37,7 +41,7 @@ def main():
     ap.add_argument("--zeros", action="store_true", help="all-zero operands (clock stays high: the DVFS bound)")
     ap.add_argument("--noout", action="store_true", help="ldc = 0: every output row aliases row 0 (output / residual traffic becomes cache hits)")
     a = ap.parse_args()
-    variants = a.variants.split(",")
+    variants = a.variants.split(";") if ";" in a.variants else a.variants.split(",")
     if a.orders:
         variants = ["o" + o for o in a.orders.split(",")]
     L = nat.lib()

@@ -8,8 +8,11 @@ from dinov2_od_amd import _native as nat
 L = nat.lib(); dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 B = int(os.environ.get("X3_B", "64")); N = 1370; D = 768; M = int(os.environ.get("X3_ROWS", B * N))
-variants = os.environ.get("X3_VARIANTS", "w,p").split(",")
+variants = os.environ.get("X3_VARIANTS", "w;p").replace(",", ";").split(";") if "@" not in os.environ.get("X3_VARIANTS", "") else os.environ["X3_VARIANTS"].split(";")
 def setv(v):
+    os.environ.pop("DINODET_GEMM_STAGGER", None)
+    if "@" in v:
+        v, st = v.split("@"); os.environ["DINODET_GEMM_STAGGER"] = st
     if v == "default": os.environ.pop("DINODET_X3_TILE", None)      # the shape heuristic
     else: os.environ["DINODET_X3_TILE"] = v
 def pair(x):
