@@ -52,11 +52,12 @@ WORKLOADS = {
 PEAK_BF16 = 2.5e15      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12
 PEAK_FP8 = 5.0e15       # dense fp8 MFMA (v_mfma_f32_32x32x64_f8f6f4), same guide
-PEAK = {"bf16": PEAK_BF16, "fp32": PEAK_F32, "fp8": PEAK_FP8, "bf16x3": PEAK_BF16}
-DOMINANT = {"bf16": "gemm_bf16", "fp32": "gemm_f32", "fp8": "gemm_fp8", "bf16x3": "gemm_bf16"}
+PEAK = {"bf16": PEAK_BF16, "fp32": PEAK_F32, "fp8": PEAK_FP8, "bf16x3": PEAK_BF16, "fp16x2": PEAK_BF16}
+DOMINANT = {"bf16": "gemm_bf16", "fp32": "gemm_f32", "fp8": "gemm_fp8", "bf16x3": "gemm_bf16", "fp16x2": "gemm_bf16"}
 KERNEL_NAMES = {"bf16": "bf16 MFMA GEMM launches of the step (gemm_bf16_* / gemm_x3_256x256_kernel<PLAIN>)", "fp32": "gemm_f32_kernel",
                 "fp8": "gemm_fp8_256x128_kernel (the e4m3 MFMA GEMM launches: QKV, out-proj, MLP-in, SwiGLU MLP-out)",
-                "bf16x3": "gemm_x3_256x256_kernel: bf16 MFMA GEMM on split operands (3 products per K step; achieved = ALGORITHMIC 2MNK FLOPs / time)"}
+                "bf16x3": "gemm_x3_256x256_kernel: bf16 MFMA GEMM on split operands (3 products per K step; achieved = ALGORITHMIC 2MNK FLOPs / time)",
+                "fp16x2": "gemm_h2_256x256_kernel: fp16 MFMA main product + both cross terms on one block-scaled e4m3 MFMA (2 bf16-equivalents per K step; achieved = ALGORITHMIC 2MNK FLOPs / time against the bf16 peak)"}
 
 
 def parse_args(argv=None):
@@ -66,7 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="vitb518", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3", "fp16x2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip parity_gated_mode / also / global64_sharded")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdinodet.so")
 
 DOD_F32, DOD_BF16 = 0, 1
-PREC = {"fp32": 0, "bf16": 1, "fp8": 2, "bf16x3": 3}
+PREC = {"fp32": 0, "bf16": 1, "fp8": 2, "bf16x3": 3, "fp16x2": 4}
 ACT = {"none": 0, "relu": 1, "gelu": 2, "sigmoid": 3}
 
 

@@ -21,6 +21,7 @@ struct WRef { const float* ptr; std::vector<int64_t> shape; const void* raw = nu
 
 struct BLayer {
   void *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;   // bf16 or fp32 by precision (fp8 mode: Wqkv, W1 and the SwiGLU W2 are e4m3)
+  unsigned char *eqkv = nullptr, *eo = nullptr, *e1 = nullptr, *e2 = nullptr;   // fp16x2 mode: per-row E8M0 exponent bytes of the H2 weight rows
   float *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;   // fp8 mode: per-output-feature dequant scales
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
   float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
@@ -118,7 +119,9 @@ struct ProfScope {
 
 inline bool is_fp8(const dod_handle* h) { return h->cfg.precision == DOD_PREC_FP8; }
 // bf16x3: the backbone block linears run as split products on the bf16 kernels; every other choice follows the fp32 mode
-inline bool is_x3(const dod_handle* h) { return h->cfg.precision == DOD_PREC_BF16X3; }
+inline bool is_x3(const dod_handle* h) { return h->cfg.precision == DOD_PREC_BF16X3 || h->cfg.precision == DOD_PREC_FP16X2; }
+// fp16x2: as bf16x3, with the four linears of every backbone block on H2-format operands (gemm_pp.hip gemm_h2_256x256_kernel)
+inline bool is_h2(const dod_handle* h) { return h->cfg.precision == DOD_PREC_FP16X2; }
 // operand dtype of everything that is not an fp8 GEMM: bf16 in both the bf16 and the fp8 mode
 inline bool is_bf16(const dod_handle* h) { return h->cfg.precision == DOD_PREC_BF16 || is_fp8(h); }
 inline size_t esz(const dod_handle* h) { return is_x3(h) ? 6 : (is_bf16(h) ? 2 : 4); }   // x3: [hi | hi | lo] bf16 per element
@@ -196,6 +199,15 @@ struct Packer {
     if (!src || cols % 32) return nullptr;
     bf16_t* b = alloc<bf16_t>((size_t)rows * 2 * cols); if (!b) return nullptr;
     if (launch_split2(src, cols, b, rows, cols, s)) { if (!rc) rc = fail(h, DOD_ERR_HIP, "split2 launch failed"); return nullptr; }
+    return b;
+  }
+  // fp16x2 mode: H2 weight rows (3 bytes per element: fp16 | e4m3 remainder) + the rows' exponent bytes (dod_common.h)
+  void* h2_w(const float* src, int rows, int cols, unsigned char** wexp_out) {
+    if (!src || cols % 32) return nullptr;
+    unsigned char* b = alloc<unsigned char>((size_t)rows * 3 * cols); unsigned char* ex = alloc<unsigned char>((size_t)rows);
+    if (!b || !ex) return nullptr;
+    if (launch_split_h2(src, cols, b, rows, cols, ex, s)) { if (!rc) rc = fail(h, DOD_ERR_HIP, "split_h2 launch failed"); return nullptr; }
+    *wexp_out = ex;
     return b;
   }
   // fp32 [rows, cols] -> e4m3 rows + per-row (output feature) scales
@@ -293,21 +305,27 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
       HIPCHK(h, hipMemcpyAsync(L.bqkv + (size_t)t * D, b, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
     }
     if (P.rc) break;
-    const bool f8 = is_fp8(h), x3 = is_x3(h);
-    L.Wqkv = x3 ? P.pair_w(cat, 3 * D, D) : f8 ? P.pack_fp8(cat, 3 * D, D, &L.sqkv) : P.pack_operand(cat, 3 * D, D, D);
-    L.Wo = x3 ? P.pair_w(P.eff_weight(lp + "attention.output.dense", D, D), D, D)
-         : f8 ? P.pack_fp8(P.eff_weight(lp + "attention.output.dense", D, D), D, D, &L.so)
-              : P.pack_operand(P.eff_weight(lp + "attention.output.dense", D, D), D, D, D);
+    const bool f8 = is_fp8(h), h2 = is_h2(h), x3 = is_x3(h) && !h2;
+    // one block linear in the precision's operand format: H2 rows + exponent bytes (fp16x2), pair layout (bf16x3), e4m3 + row scales
+    // (fp8; GELU-MLP fc2 stays bf16), else bf16 / fp32
+    auto packw = [&](const float* w, int rows, int cols, float** sc, unsigned char** ex, bool fp8_ok) -> void* {
+      if (h2) return P.h2_w(w, rows, cols, ex);
+      if (x3) return P.pair_w(w, rows, cols);
+      if (f8 && fp8_ok) return P.pack_fp8(w, rows, cols, sc);
+      return P.pack_operand(w, rows, cols, cols);
+    };
+    L.Wqkv = packw(cat, 3 * D, D, &L.sqkv, &L.eqkv, true);
+    L.Wo = packw(P.eff_weight(lp + "attention.output.dense", D, D), D, D, &L.so, &L.eo, true);
     L.bo = P.eff_bias(lp + "attention.output.dense", D);
     if (c.swiglu) {
-      L.W1 = x3 ? P.pair_w(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, D);
+      L.W1 = packw(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, &L.s1, &L.e1, true);
       L.b1 = P.eff_bias(lp + "mlp.weights_in", 2 * F);
-      L.W2 = x3 ? P.pair_w(P.eff_weight(lp + "mlp.weights_out", D, F), D, F) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, &L.s2) : P.pack_operand(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, F);
+      L.W2 = packw(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, &L.s2, &L.e2, true);
       L.b2 = P.eff_bias(lp + "mlp.weights_out", D);
     } else {
-      L.W1 = x3 ? P.pair_w(P.eff_weight(lp + "mlp.fc1", F, D), F, D) : f8 ? P.pack_fp8(P.eff_weight(lp + "mlp.fc1", F, D), F, D, &L.s1) : P.pack_operand(P.eff_weight(lp + "mlp.fc1", F, D), F, D, D);
+      L.W1 = packw(P.eff_weight(lp + "mlp.fc1", F, D), F, D, &L.s1, &L.e1, true);
       L.b1 = P.eff_bias(lp + "mlp.fc1", F);
-      L.W2 = x3 ? P.pair_w(P.eff_weight(lp + "mlp.fc2", D, F), D, F) : P.pack_operand(P.eff_weight(lp + "mlp.fc2", D, F), D, F, F);
+      L.W2 = packw(P.eff_weight(lp + "mlp.fc2", D, F), D, F, &L.s2, &L.e2, false);
       L.b2 = P.eff_bias(lp + "mlp.fc2", D);
     }
   }
@@ -490,6 +508,14 @@ int linear3(dod_handle* h, const void* A3, const void* W3, int M, int N, int K, 
   if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "bf16x3 linear launch rejected (M=%d N=%d K=%d rc=%d)", M, N, K, r);
   return 0;
 }
+// fp16x2 linear on H2-format operands (activation rows 4K bytes, weight rows 3K bytes + exponent bytes; algorithmic FLOPs reported)
+int linear_h2(dod_handle* h, const void* A, const void* W, const unsigned char* wexp, int M, int N, int K, GemmEpi e, hipStream_t s) {
+  ProfScope ps(h, s, PC_GEMM_BF16, 2.0 * M * N * (double)K);
+  e.h2_wexp = wexp;
+  int r = launch_gemm_h2(A, 4 * K, W, 3 * K, M, N, K, e, s);
+  if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "fp16x2 linear launch rejected (M=%d N=%d K=%d rc=%d)", M, N, K, r);
+  return 0;
+}
 // fp8 linear: A_q [M,K] e4m3 with per-row scales, W_q [N,K] e4m3 with per-row (output feature) scales
 int linear8(dod_handle* h, const void* A, const float* a_scale, const void* W, const float* w_scale, int M, int N, int K, GemmEpi e, hipStream_t s) {
   ProfScope ps(h, s, PC_GEMM_FP8, 2.0 * M * N * (double)K);
@@ -546,17 +572,24 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   const int nblocks = stop_blocks >= 0 ? (stop_blocks < g.layers ? stop_blocks : g.layers) : g.layers;
   for (int i = 0; i < nblocks; ++i) {
     const BLayer& L = h->L[i];
-    if (x3) {   // bf16x3: every block linear as a split product on the bf16 kernels; attention and LayerNorm in fp32
-      bf16_t* y3 = (bf16_t*)ws.y;
-      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3)); }
-      if (D / g.heads == 64) {   // split-product flash attention on the bf16 MFMA cores
+    if (x3) {   // bf16x3 / fp16x2: every block linear as a compensated product on the bf16 / fp16+e4m3 kernels; attention and LayerNorm in fp32
+      const bool h2 = is_h2(h);
+      bf16_t* y3 = (bf16_t*)ws.y;       // pair layout [hi | lo] (bf16x3) or H2 rows (fp16x2): 4 bytes per element either way
+      auto lin = [&](const void* A, const void* Wp, const unsigned char* ex, int Nn, int Kk, const GemmEpi& e) -> int {
+        return h2 ? linear_h2(h, A, Wp, ex, M, Nn, Kk, e, s) : linear3(h, A, Wp, M, Nn, Kk, e, s);
+      };
+      auto split = [&](const float* src, int cols, void* dst) -> int {
+        return h2 ? launch_split_h2(src, cols, dst, M, cols, nullptr, s) : launch_split2(src, cols, (bf16_t*)dst, M, cols, s);
+      };
+      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3, h2 ? 1 : 0)); }
+      if (D / g.heads == 64) {   // split-product flash attention on the bf16 MFMA cores (both modes: its q / k / v stay bf16 pairs)
         GemmEpi eq = epi(L.bqkv, nullptr, ws.qkv, 6 * D);
         eq.out_split = -3 * D;       // [hi(q|k|v) | lo(q|k|v)]
-        rc = linear3(h, y3, L.Wqkv, M, 3 * D, D, eq, s); if (rc) return rc;
+        rc = lin(y3, L.Wqkv, L.eqkv, 3 * D, D, eq); if (rc) return rc;
         ProfScope ps(h, s, PC_ATTN_BF16, 4.0 * B * (double)N * N * D);
-        KCHK(h, launch_attn_x3((const bf16_t*)ws.qkv, (bf16_t*)ws.ctx, B, N, g.heads, scale, s));
+        KCHK(h, launch_attn_x3((const bf16_t*)ws.qkv, (bf16_t*)ws.ctx, B, N, g.heads, scale, s, h2 ? 1 : 0));
       } else {                    // other head sizes (micro test models): generic fp32 attention, then split
-        rc = linear3(h, y3, L.Wqkv, M, 3 * D, D, epi(L.bqkv, (float*)ws.qkv, nullptr, 3 * D), s); if (rc) return rc;
+        rc = lin(y3, L.Wqkv, L.eqkv, 3 * D, D, epi(L.bqkv, (float*)ws.qkv, nullptr, 3 * D)); if (rc) return rc;
         float* ctxf = (float*)ws.hbuf;
         {
           ProfScope ps(h, s, PC_ATTN_F32, 4.0 * B * (double)N * N * D);
@@ -565,20 +598,21 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
           a.Lq = a.Lk = N; a.B = B; a.heads = g.heads; a.dh = D / g.heads; a.scale = scale;
           KCHK(h, launch_attn_f32(a, s));
         }
-        KCHK(h, launch_split2(ctxf, D, (bf16_t*)ws.ctx, M, D, s));
+        KCHK(h, split(ctxf, D, ws.ctx));
       }
-      rc = linear3(h, ws.ctx, L.Wo, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;
-      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3)); }
+      rc = lin(ws.ctx, L.Wo, L.eo, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D)); if (rc) return rc;
+      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3, h2 ? 1 : 0)); }
       if (g.swiglu) {
-        rc = linear3(h, y3, L.W1, M, 2 * F, D, epi(L.b1, (float*)ws.hbuf, nullptr, 2 * F), s); if (rc) return rc;
+        rc = lin(y3, L.W1, L.e1, 2 * F, D, epi(L.b1, (float*)ws.hbuf, nullptr, 2 * F)); if (rc) return rc;
         KCHK(h, launch_swiglu((const float*)ws.hbuf, nullptr, M, F, (float*)ws.gated, nullptr, s));
-        KCHK(h, launch_split2((const float*)ws.gated, F, (bf16_t*)ws.hbuf, M, F, s));
+        KCHK(h, split((const float*)ws.gated, F, ws.hbuf));
       } else {
         GemmEpi e1 = epi(L.b1, nullptr, ws.hbuf, 2 * F, ACT_GELU);
-        e1.out_split = -F;            // pair layout [hi | lo]
-        rc = linear3(h, y3, L.W1, M, F, D, e1, s); if (rc) return rc;
+        if (h2) e1.out_h2 = 1;        // H2 rows
+        else e1.out_split = -F;       // pair layout [hi | lo]
+        rc = lin(y3, L.W1, L.e1, F, D, e1); if (rc) return rc;
       }
-      rc = linear3(h, ws.hbuf, L.W2, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
+      rc = lin(ws.hbuf, L.W2, L.e2, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D)); if (rc) return rc;
       tap(h, 1 + i, ws.x, false, (size_t)M * D, s);
       continue;
     }
@@ -802,7 +836,7 @@ int dod_create(const dod_config* cfg, dod_handle** out) {
   if (!c.target_dim && c.hidden != c.dec_hidden) return fail(nullptr, DOD_ERR_INVALID, "backbone width %d != decoder hidden %d and no projection", c.hidden, c.dec_hidden);
   if (c.use_deformable && (c.n_points <= 0 || c.n_points > 8)) return fail(nullptr, DOD_ERR_INVALID, "n_points must be 1..8");
   if (c.dec_layers > 64) return fail(nullptr, DOD_ERR_INVALID, "at most 64 decoder layers");
-  if (c.precision != DOD_PREC_FP32 && c.precision != DOD_PREC_BF16 && c.precision != DOD_PREC_FP8 && c.precision != DOD_PREC_BF16X3) return fail(nullptr, DOD_ERR_INVALID, "unknown precision %d", c.precision);
+  if (c.precision != DOD_PREC_FP32 && c.precision != DOD_PREC_BF16 && c.precision != DOD_PREC_FP8 && c.precision != DOD_PREC_BF16X3 && c.precision != DOD_PREC_FP16X2) return fail(nullptr, DOD_ERR_INVALID, "unknown precision %d", c.precision);
   dod_handle* h = new (std::nothrow) dod_handle();
   if (!h) return fail(nullptr, DOD_ERR_STATE, "out of host memory");
   h->cfg = c;

@@ -673,7 +673,7 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
   }
   const int gm = gemm_tile_mode();
   const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
-  if (getenv("DINODET_DEBUG_LDA0")) lda = 0;      // tuning only: every A row aliases row 0 (A traffic becomes cache hits)
+  if (const char* v = getenv("DINODET_DEBUG_LDA0")) lda = atoi(v) & ~15;   // tuning only: A row pitch override (0: every row aliases row 0; 64: 16-row pieces contiguous)
   hipLaunchKernelGGL(gemm_h2_256x256_kernel, dim3(tiles), dim3(512), LDSH2, s, (const char*)A, lda, (const char*)W, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

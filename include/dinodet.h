@@ -49,9 +49,13 @@ enum dod_precision {
   DOD_PREC_BF16X3 = 3,      /* backbone linears as bf16x3 split products on the bf16 MFMA kernels (A = Ah + Al, W = Wh + Wl,
                                Ah Wh + Ah Wl + Al Wh: ~1e-5 relative, fp32-class accuracy at a third of the bf16 rate);
                                everything else as FP32.  A parity-gated mode that runs on the bf16 matrix cores   */
-  DOD_PREC_FP8 = 2          /* as BF16, with the QKV / MLP-in (/ SwiGLU MLP-out) linears on OCP e4m3 MFMA operands:
+  DOD_PREC_FP8 = 2,         /* as BF16, with the QKV / MLP-in (/ SwiGLU MLP-out) linears on OCP e4m3 MFMA operands:
                                per-token activation scales from the producing LayerNorm / SwiGLU kernel, per-output-
                                feature weight scales (BASELINE configs[4]: ViT-g/14 fp8)          */
+  DOD_PREC_FP16X2 = 4       /* as BF16X3, with the four linears of every backbone block as fp16 main product + both cross terms
+                               on ONE block-scaled e4m3 MFMA (x = fp16(x) + remainder; 2.0 bf16-MFMA-equivalents per product
+                               instead of 3; ~2e-5 relative per linear).  Parity-gated like BF16X3; operands limited to the
+                               fp16 range (|x| <= 65504, clamped beyond)                          */
 };
 
 /* Shapes.  Backbone fields mirror HF Dinov2Config as used by dinov2_backbone.py:11-27; decoder
