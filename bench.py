@@ -27,7 +27,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
                  MFMA cores, within the 1e-3 gate), with its own value / roofline / gpu_vs_oracle -- measured exactly like the
                  headline (N = 1 only);
   also         : BASELINE configs[1] (ViT-B/14 224x224, batch 32) in both modes (N = 1 only).
-Other workloads / modes: --workload {vits224,vitb224,vitl518,vitg518}, --precision {bf16,bf16x3,fp32,fp8}.
+Other workloads / modes: --workload {vits224,vitb224,vitl518,vitg518}, --precision {bf16,bf16x3,fp16x2,fp32,fp8}.
 `--rehearse-cpu` swaps the model for a stub on the CPU with gloo: it exercises launcher, sharding, barriers, timing and the
 overlapped gather without a GPU (tests/test_dist_cpu.py) and labels its line as a rehearsal -- never a measurement.
 """
@@ -446,6 +446,13 @@ def worker(a):
                                                     "roofline.achieved counts ALGORITHMIC FLOPs")
             except Exception as e:
                 res["parity_gated_mode"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                res["fp16x2_mode"] = measure_mode(name, Q, R, "fp16x2", x, max(5, a.steps // 4), max(2, a.warmup // 4), device, use_graph, oracle_first)
+                res["fp16x2_mode"]["note"] = ("the second parity-gated mode (opt-in): the block linears as fp16 main product + both cross terms on one "
+                                              "block-scaled e4m3 MFMA (2 bf16-MFMA-equivalents per product instead of 3), everything else as bf16x3; "
+                                              "roofline.achieved counts ALGORITHMIC FLOPs against the bf16 peak")
+            except Exception as e:
+                res["fp16x2_mode"] = {"error": f"{type(e).__name__}: {e}"}
             if a.workload == "vitb518":
                 res["also"] = {}
                 n2, R2, Q2, B2, d2 = WORKLOADS["vitb224"]
