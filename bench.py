@@ -310,7 +310,7 @@ def roofline_leg(model, x, precision, steps, traffic=None, traffic_src=None):
 def pmc_traffic(workload, precision, B_local):
     """HBM-side bytes per launch of the dominant kernel class from the committed rocprofv3 --pmc passes of this same command
     (separate runs: not measurable live); latest round's file"""
-    for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         try:
             tdat = json.load(open(tj))
         except Exception:

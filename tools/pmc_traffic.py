@@ -32,7 +32,7 @@ for k, d in a.items():
         h, m = sum(b[k]["TCC_HIT_sum"]), sum(b[k]["TCC_MISS_sum"])
         e["l2_hit_rate"] = h / max(1.0, h + m)
     per[k] = e
-gemm = {k: v for k, v in per.items() if k.startswith("gemm_bf16") or k.startswith("void gemm_bf16") or "gemm_x3" in k or "gemm_pp" in k or "patch_embed" in k}
+gemm = {k: v for k, v in per.items() if k.startswith("gemm_bf16") or k.startswith("void gemm_bf16") or "gemm_x3" in k or "gemm_pp" in k or "gemm_h2" in k or "patch_embed" in k}
 n = sum(v["launches_profiled"] for v in gemm.values())
 avg = sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in gemm.values()) / max(1, n)
 json.dump({"workload": bench_workload, "precision": precision, "batch": int(batch), "command": desc, "source": "rocprofv3 --pmc FETCH_SIZE WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum (separate passes)",
