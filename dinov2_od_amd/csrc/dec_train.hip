@@ -338,180 +338,16 @@ __global__ __launch_bounds__(256) void mha_bwd_col_kernel(const float* __restric
   if (d1) { dk[lane + 64] = k1 * scale; dv[lane + 64] = v1; }
 }
 
-// ---- the same three passes with the (image, head)'s operands staged in LDS: ONE workgroup per (b, head), K and V (then Q and dO)
-// as [N][dh + 1] fp32 (the +1 keeps the lane-per-key row reads conflict-free), every wave walks rows (then columns) w, w+4, ...
-// The global-memory forms above re-read each key row from L2 for every query row (3 passes x N x dh floats per row: 1.5 ms for the
-// 257 tokens x 12 heads x 16 images of a ViT-B block); these run out of LDS.  Used whenever the operands fit (mha_lds_bytes).
-__host__ __device__ inline size_t mha_lds_bytes(int Q, int dh) { return ((size_t)2 * Q * (dh + 1) + (size_t)8 * Q) * 4; }
-
-__device__ __forceinline__ void mha_stage2(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int Q, int dh, float* sa, float* sb, int tid) {
-  const int nvec = dh >> 2, ldp = dh + 1;
-  for (int i = tid; i < Q * nvec; i += 256) {
-    const int r = i / nvec, c = (i - r * nvec) * 4;
-    const float4 x = *reinterpret_cast<const float4*>(a + (size_t)r * lda + c), y = *reinterpret_cast<const float4*>(b + (size_t)r * ldb + c);
-    float* pa = sa + r * ldp + c; float* pb = sb + r * ldp + c;
-    pa[0] = x.x; pa[1] = x.y; pa[2] = x.z; pa[3] = x.w;
-    pb[0] = y.x; pb[1] = y.y; pb[2] = y.z; pb[3] = y.w;
-  }
-}
-// probabilities of row i against the LDS-resident K (scores, softmax) -> sp[0..Q)
-__device__ __forceinline__ void mha_row_probs_lds(const float* __restrict__ qi, const float* sK, int Q, int dh, float scale, float* sp, int lane) {
-  const int ldp = dh + 1;
-  float mx = -INFINITY;
-  for (int j = lane; j < Q; j += 64) {
-    const float* kj = sK + j * ldp;
-    float acc = 0.f;
-    for (int d = 0; d < dh; d += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(qi + d);
-      acc += a.x * kj[d] + a.y * kj[d + 1] + a.z * kj[d + 2] + a.w * kj[d + 3];
-    }
-    acc *= scale;
-    sp[j] = acc;
-    mx = fmaxf(mx, acc);
-  }
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int j = lane; j < Q; j += 64) { const float e = expf(sp[j] - mx); sp[j] = e; sum += e; }
-  sum = wave_sum(sum);
-  const float inv = 1.0f / sum;
-  for (int j = lane; j < Q; j += 64) sp[j] *= inv;
-}
-
-__global__ __launch_bounds__(256) void mha_fwd_train_lds_kernel(const float* __restrict__ qkv, int ld, float* __restrict__ out, int ldo, int Q, int Hd,
-                                                                int Dd, int dh, float scale, float p, unsigned long long key) {
-  extern __shared__ __attribute__((aligned(16))) float lsm[];
-  const int ldp = dh + 1;
-  float* sK = lsm; float* sV = sK + Q * ldp; float* sPall = sV + Q * ldp;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int bh = blockIdx.x, h = bh % Hd, b = bh / Hd;
-  const float* base = qkv + (size_t)b * Q * ld + h * dh;
-  mha_stage2(base + Dd, ld, base + 2 * Dd, ld, Q, dh, sK, sV, tid);
-  __syncthreads();
-  float* sp = sPall + w * Q;
-  const bool d0 = lane < dh, d1 = lane + 64 < dh;
-  for (int i = w; i < Q; i += 4) {
-    mha_row_probs_lds(base + (size_t)i * ld, sK, Q, dh, scale, sp, lane);
-    if (p > 0.f) {
-      const float inv = 1.0f / (1.0f - p);
-      const unsigned long long item = (unsigned long long)bh * Q + i;
-      for (int j = lane; j < Q; j += 64) sp[j] = u01(key, item * Q + j) >= p ? sp[j] * inv : 0.f;
-    }
-    float o0 = 0.f, o1 = 0.f;
-    for (int j = 0; j < Q; ++j) {
-      const float pj = sp[j];
-      if (d0) o0 += pj * sV[j * ldp + lane];
-      if (d1) o1 += pj * sV[j * ldp + lane + 64];
-    }
-    float* op = out + ((size_t)b * Q + i) * ldo + h * dh;
-    if (d0) op[lane] = o0;
-    if (d1) op[lane + 64] = o1;
-  }
-}
-
-__global__ __launch_bounds__(256) void mha_bwd_lds_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dO, int ldo,
-                                                          float* __restrict__ dqkv, float* __restrict__ dS, float* __restrict__ Pd, int Q, int Hd,
-                                                          int Dd, int dh, float scale, float p, unsigned long long key) {
-  extern __shared__ __attribute__((aligned(16))) float lsm[];
-  const int ldp = dh + 1;
-  float* sA = lsm; float* sB = sA + Q * ldp; float* sPall = sB + Q * ldp; float* sDall = sPall + 4 * Q;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int bh = blockIdx.x, h = bh % Hd, b = bh / Hd;
-  const float* base = qkv + (size_t)b * Q * ld + h * dh;
-  const float* dob = dO + (size_t)b * Q * ldo + h * dh;
-  float* dSb = dS + (size_t)bh * Q * Q;
-  float* Pdb = Pd + (size_t)bh * Q * Q;
-  const bool d0 = lane < dh, d1 = lane + 64 < dh;
-  const float inv = 1.0f / (1.0f - p);
-  // ---- rows: K, V resident
-  mha_stage2(base + Dd, ld, base + 2 * Dd, ld, Q, dh, sA, sB, tid);
-  __syncthreads();
-  float* sp = sPall + w * Q;
-  float* sd = sDall + w * Q;
-  for (int i = w; i < Q; i += 4) {
-    mha_row_probs_lds(base + (size_t)i * ld, sA, Q, dh, scale, sp, lane);
-    const float* doi = dob + (size_t)i * ldo;
-    const unsigned long long item = (unsigned long long)bh * Q + i;
-    float dot = 0.f;
-    for (int j = lane; j < Q; j += 64) {
-      const float* vj = sB + j * ldp;
-      float acc = 0.f;
-      for (int d = 0; d < dh; d += 4) {
-        const float4 a = *reinterpret_cast<const float4*>(doi + d);
-        acc += a.x * vj[d] + a.y * vj[d + 1] + a.z * vj[d + 2] + a.w * vj[d + 3];
-      }
-      float keepf = 1.0f;
-      if (p > 0.f) keepf = u01(key, item * Q + j) >= p ? inv : 0.f;
-      const float dP = acc * keepf;
-      sd[j] = dP;
-      dot += dP * sp[j];
-      Pdb[(size_t)i * Q + j] = sp[j] * keepf;
-    }
-    dot = wave_sum(dot);
-    for (int j = lane; j < Q; j += 64) {
-      const float ds = sp[j] * (sd[j] - dot);
-      sd[j] = ds;
-      dSb[(size_t)i * Q + j] = ds;
-    }
-    float q0 = 0.f, q1 = 0.f;
-    for (int j = 0; j < Q; ++j) {
-      const float ds = sd[j];
-      if (d0) q0 += ds * sA[j * ldp + lane];
-      if (d1) q1 += ds * sA[j * ldp + lane + 64];
-    }
-    float* dq = dqkv + ((size_t)b * Q + i) * ld + h * dh;
-    if (d0) dq[lane] = q0 * scale;
-    if (d1) dq[lane + 64] = q1 * scale;
-  }
-  __syncthreads();                      // every row's dS / Pd is written (same CU: visible after the barrier); K, V are dead
-  // ---- columns: Q, dO resident
-  mha_stage2(base, ld, dob, ldo, Q, dh, sA, sB, tid);
-  __syncthreads();
-  for (int j = w; j < Q; j += 4) {
-    float k0 = 0.f, k1 = 0.f, v0 = 0.f, v1 = 0.f;
-    for (int i = 0; i < Q; ++i) {
-      const float ds = dSb[(size_t)i * Q + j], pd = Pdb[(size_t)i * Q + j];
-      if (d0) { k0 += ds * sA[i * ldp + lane]; v0 += pd * sB[i * ldp + lane]; }
-      if (d1) { k1 += ds * sA[i * ldp + lane + 64]; v1 += pd * sB[i * ldp + lane + 64]; }
-    }
-    float* dk = dqkv + ((size_t)b * Q + j) * ld + Dd + h * dh;
-    float* dv = dqkv + ((size_t)b * Q + j) * ld + 2 * Dd + h * dh;
-    if (d0) { dk[lane] = k0 * scale; dv[lane] = v0; }
-    if (d1) { dk[lane + 64] = k1 * scale; dv[lane + 64] = v1; }
-  }
-}
-
-// launchers: the LDS-resident forms whenever one (image, head)'s operands fit a CU's LDS and rows are float4-addressable
-static inline bool mha_use_lds(int Q, int dh, int ld, int ldo) {
-  return dh % 4 == 0 && dh <= 128 && ld % 4 == 0 && ldo % 4 == 0 && mha_lds_bytes(Q, dh) <= (size_t)160 * 1024;
-}
-static void mha_lds_attr(size_t bytes) {
-  static size_t set_to[16] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16 || set_to[dev] >= bytes) return;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_fwd_train_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_bwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  set_to[dev] = (size_t)160 * 1024;
-}
+// (An LDS-resident variant -- one workgroup per (image, head), K / V then Q / dO staged as [N][dh + 1] fp32 -- was built and measured
+// on the ViT-B tail, 257 tokens x 12 heads x 16 images: 1 803 us for the backward against 589 + 258 us for the two kernels above, and
+// 373 against 175 us for the forward: 192 workgroups of four waves leave every SIMD with one latency-bound wave.  Not kept.)
 static hipError_t launch_mha_fwd_train(const float* qkv, int ld, float* out, int ldo, int B, int Q, int Hd, int Dd, int dh, float scale, float p,
                                        unsigned long long key, hipStream_t s) {
-  if (mha_use_lds(Q, dh, ld, ldo)) {
-    const size_t lds = mha_lds_bytes(Q, dh);
-    mha_lds_attr(lds);
-    hipLaunchKernelGGL(mha_fwd_train_lds_kernel, dim3((unsigned)(B * Hd)), dim3(256), lds, s, qkv, ld, out, ldo, Q, Hd, Dd, dh, scale, p, key);
-  } else {
-    hipLaunchKernelGGL(mha_fwd_train_kernel, dim3((unsigned)(((long)B * Hd * Q + 3) / 4)), dim3(256), 0, s, qkv, ld, out, ldo, B, Q, Hd, Dd, dh, scale, p, key);
-  }
+  hipLaunchKernelGGL(mha_fwd_train_kernel, dim3((unsigned)(((long)B * Hd * Q + 3) / 4)), dim3(256), 0, s, qkv, ld, out, ldo, B, Q, Hd, Dd, dh, scale, p, key);
   return hipGetLastError();
 }
 static hipError_t launch_mha_bwd(const float* qkv, int ld, const float* dO, int ldo, float* dqkv, float* dS, float* Pd, int B, int Q, int Hd, int Dd,
                                  int dh, float scale, float p, unsigned long long key, hipStream_t s) {
-  if (mha_use_lds(Q, dh, ld, ldo)) {
-    const size_t lds = mha_lds_bytes(Q, dh);
-    mha_lds_attr(lds);
-    hipLaunchKernelGGL(mha_bwd_lds_kernel, dim3((unsigned)(B * Hd)), dim3(256), lds, s, qkv, ld, dO, ldo, dqkv, dS, Pd, Q, Hd, Dd, dh, scale, p, key);
-    return hipGetLastError();
-  }
   const unsigned nb = (unsigned)(((long)B * Hd * Q + 3) / 4);
   hipLaunchKernelGGL(mha_bwd_row_kernel, dim3(nb), dim3(256), 0, s, qkv, ld, dO, ldo, dqkv, dS, Pd, B, Q, Hd, Dd, dh, scale, p, key);
   hipError_t e = hipGetLastError();
