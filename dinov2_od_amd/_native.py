@@ -106,6 +106,8 @@ SYMBOLS = {
     "dod_backbone_tail_workspace_bytes": (_SZ, [C.POINTER(DodConfig), _I, _I, _I]),
     "dod_backbone_tail_train_forward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _P, _P, _SZ, _P, _SZ, _P]),
     "dod_backbone_tail_train_backward": (_I, [C.POINTER(DodConfig), _P, _I, _I, _P, _P, _SZ, _P, _P, _SZ, _P]),
+    "dod_reserve_gemm_scratch": (_I, [C.c_size_t]),
+    "dod_debug_tail_splits": (C.c_long, []),
     "dod_debug_gemm_stamps": (_I, [_P]),
     "dod_debug_pp_stamps": (_I, [_P]),
     "dod_debug_attn_stamps": (_I, [_P]),

@@ -865,8 +865,11 @@ int dod_set_weight(dod_handle* h, const char* key, const void* dev_ptr, const in
   return DOD_OK;
 }
 
+int dod_reserve_gemm_scratch(size_t bytes) { return gemm_tail_reserve(bytes) ? fail(nullptr, DOD_ERR_HIP, "scratch allocation of %zu bytes failed", bytes) : DOD_OK; }
+
 int dod_finalize_weights(dod_handle* h, void* stream) {
   if (!h) return fail(nullptr, DOD_ERR_INVALID, "null handle");
+  (void)gemm_tail_reserve((size_t)64 << 20);     // K-split scratch of the GEMMs' wave-quantisation tail (gemm_pp.hip): never allocated inside a forward
   return finalize_impl(h, (hipStream_t)stream);
 }
 

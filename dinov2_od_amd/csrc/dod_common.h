@@ -112,6 +112,9 @@ struct GemmEpi {
   const float* w_scale;   // fp8 GEMM only: per-output-feature dequant scale of W, [N]
   int out_h2;             // with out_bf16: H2 activation rows (above) of N columns at row pitch ldc (2-byte units, >= 2N)
   const unsigned char* h2_wexp;   // H2 GEMM only: E8M0 byte (127 - e) of every weight row's e4m3 scale 2^e, [N]
+  int ksplit;             // ping-pong / H2 kernels only: > 1 = the grid's y index is a K slice of kslice_len k; the slice's fp32 partial
+  int kslice_len;         //   product goes to out_f32 + slice * kslice_stride (no other epilogue term may be set)
+  long long kslice_stride;
 };
 
 // ----------------------------------------------------------------------------- launchers (all enqueue on `s`, no sync)
@@ -180,6 +183,13 @@ int launch_split2(const float* in, int ld_in, bf16_t* out, int rows, int K, hipS
 int launch_split_h2(const float* in, int ld_in, void* out, int rows, int K, unsigned char* wexp, hipStream_t s);
 // H2 GEMM (gemm_pp.hip): A [M, K] activation rows (pitch lda BYTES >= 4K), W [N, K] weight rows (pitch ldw BYTES >= 3K), e.h2_wexp set
 int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
+// Wave-quantisation tail of the 256x256-tile GEMMs (gemm_pp.hip): when tiles % CUs leaves a short last round (1029 tiles on 256
+// CUs: a fifth round for five tiles, +24 %), the rows of that round are cut off the main launch and computed by a K-SPLIT launch
+// (every tile of the remainder as S slices on S CUs, fp32 partials to a scratch buffer) plus a reduce + epilogue launch.
+// kind: 0 plain bf16 (ppm kernel), 1 split product, 2 H2.  Returns 0 when done, -1 when the shape does not qualify (caller
+// launches normally), > 0 on error.  gemm_tail_reserve(bytes): allocate the scratch outside any stream capture.
+int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
+int gemm_tail_reserve(size_t bytes);
 // split-product GEMM on pair-layout operands A2 [M, 2K], W2 [N, 2K] (gemm_x3.hip)
 int launch_gemm_bf16_k64(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 int gemm_tile_mode();   // tile-order mode word of the 256-row kernels (gemm_x3.hip; gemm_epi.h tile_map)

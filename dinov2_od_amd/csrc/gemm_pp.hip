@@ -22,6 +22,7 @@
 #include "dod_common.h"
 #include "gemm_epi.h"
 #include <cstdlib>
+#include <cstring>
 
 #define PPM 256
 #define PPN 256
@@ -194,7 +195,7 @@ extern "C" int dod_debug_pp_stamps(void* dev_buf) {
 template <bool X3, bool DC>
 __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __restrict__ A, int lda,
                                                                const bf16_t* __restrict__ W, int ldw, int M, int N,
-                                                               int K, GemmEpi e, int GM) {
+                                                               int K, GemmEpi e_, int GM) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wu = __builtin_amdgcn_readfirstlane(wid);
@@ -206,6 +207,11 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
   int tm, tn;
   tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
   const int m0 = tm * PPM, n0 = tn * PPN;
+  // K slice (gemm_tail_split): this workgroup computes k in [kbase, kbase + Kl) and writes its fp32 partial to its own slab
+  const int Kl = e_.ksplit > 1 ? e_.kslice_len : K;
+  const int kbase = e_.ksplit > 1 ? (int)blockIdx.y * Kl : 0;
+  GemmEpi e = e_;
+  if (e_.ksplit > 1) e.out_f32 = e_.out_f32 + (size_t)blockIdx.y * (size_t)e_.kslice_stride;
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   // staging through buffer descriptors: wave-uniform base in SGPRs, one 32-bit byte offset per lane (computed once), the
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
 #define PPM_STAGE_H(t, pl, hh)                                                                                 \
   {                                                                                                            \
     char* d_ = sdst + ((t) & 1) * PP_TILE + (pl) * PP_PLANE + (hh) * 1024;                                     \
-    const int ko_ = ((t) * KT + (((pl) & 1) ? pl1 : 0)) * 2;                                                   \
+    const int ko_ = (kbase + (t) * KT + (((pl) & 1) ? pl1 : 0)) * 2;                                                   \
     if ((pl) < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(d_), 16, (hh) ? vA1 : vA0, ko_, 0, 0); \
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(d_), 16, (hh) ? vW1 : vW0, ko_, 0, 0);          \
   }
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nk = K / KT;
+  const int nk = Kl / KT;
   const int l15 = lane & 15, l4 = lane >> 4;
   int offA[8], offW[4];
 #pragma unroll
@@ -398,7 +404,7 @@ __device__ __forceinline__ void h2_cvt8(const bf16x8& raw, float inv_scale, int&
 }
 
 __global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __restrict__ A, int lda, const char* __restrict__ W, int ldw,
-                                                              int M, int N, int K, GemmEpi e, int GM) {
+                                                              int M, int N, int K, GemmEpi e_, int GM) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wu = __builtin_amdgcn_readfirstlane(wid);
@@ -410,6 +416,11 @@ __global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __rest
   int tm, tn;
   tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
   const int m0 = tm * PPM, n0 = tn * PPN;
+  // K slice (gemm_tail_split): k-tiles [kb, kb + nk) of the operands, fp32 partial to this slice's slab
+  const int Kl = e_.ksplit > 1 ? e_.kslice_len : K;
+  const int kb = e_.ksplit > 1 ? (int)blockIdx.y * (Kl / 32) : 0;
+  GemmEpi e = e_;
+  if (e_.ksplit > 1) e.out_f32 = e_.out_f32 + (size_t)blockIdx.y * (size_t)e_.kslice_stride;
   typedef __attribute__((address_space(3))) void* lptr_t;
   // staging (buffer-descriptor LDS-DMA): 64-byte planes as two 16-row pieces per wave (lane -> row = lane >> 2, LDS chunk slot
   // lane & 3, fetching global chunk slot ^ swizzle(row)); the 32-byte W remainder plane as ONE 32-row piece (row = lane >> 1)
@@ -433,17 +444,17 @@ __global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __rest
 #define H2_STAGE_A(t, ab)                                                                                      \
   {                                                                                                            \
     char* b_ = smem + (ab) * H2_ABUF + wu * 2048;                                                              \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_), 16, vA0, (t) * 64, 0, 0);                       \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_ + 1024), 16, vA1, (t) * 64, 0, 0);                \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_ + H2_A8), 16, vA0, K2 + (t) * 64, 0, 0);          \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_ + H2_A8 + 1024), 16, vA1, K2 + (t) * 64, 0, 0);   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_), 16, vA0, (kb + (t)) * 64, 0, 0);                       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_ + 1024), 16, vA1, (kb + (t)) * 64, 0, 0);                \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_ + H2_A8), 16, vA0, K2 + (kb + (t)) * 64, 0, 0);          \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(b_ + H2_A8 + 1024), 16, vA1, K2 + (kb + (t)) * 64, 0, 0);   \
   }
 #define H2_STAGE_W(t)                                                                                          \
   {                                                                                                            \
     char* b_ = smem + H2_WBASE + ((t) & 1) * H2_WBUF;                                                          \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(b_ + wu * 2048), 16, vW0, (t) * 64, 0, 0);           \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(b_ + wu * 2048 + 1024), 16, vW1, (t) * 64, 0, 0);    \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(b_ + H2_WL + wu * 1024), 16, vWl, (t) * 32, 0, 0);   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(b_ + wu * 2048), 16, vW0, (kb + (t)) * 64, 0, 0);           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(b_ + wu * 2048 + 1024), 16, vW1, (kb + (t)) * 64, 0, 0);    \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(b_ + H2_WL + wu * 1024), 16, vWl, (kb + (t)) * 32, 0, 0);   \
   }
   f32x16 acc[4][2];
 #pragma unroll
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __rest
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int nk = K / 32;
+  const int nk = Kl / 32;
   const int lr = lane & 31, lg = lane >> 5;
   int offA[4], offW[2], offWl[2];
 #pragma unroll
@@ -663,6 +674,7 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
   if (e.out_h2 && (N % 32 != 0 || e.ldc < 2 * N || e.ldc % 8 != 0 || e.out_split != 0)) return 2;
+  { const int t = gemm_tail_split(2, A, lda, W, ldw, M, N, K, e, s); if (t >= 0) return t; }
   constexpr int LDSH2 = (128 * (PPN * 4 + 16)) > H2_LDS ? (128 * (PPN * 4 + 16)) : H2_LDS;
   static bool attr_set[16] = {};
   int dev = 0;
@@ -675,5 +687,117 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
   const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
   if (const char* v = getenv("DINODET_DEBUG_LDA0")) lda = atoi(v) & ~15;   // tuning only: A row pitch override (0: every row aliases row 0; 64: 16-row pieces contiguous)
   hipLaunchKernelGGL(gemm_h2_256x256_kernel, dim3(tiles), dim3(512), LDSH2, s, (const char*)A, lda, (const char*)W, ldw, M, N, K, e, gm);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Wave-quantisation tail (dod_common.h gemm_tail_split).  One 256x256 tile per CU and round: 343 x 3 = 1029 tiles of an N = 768 GEMM at
+// M = 87680 take FIVE rounds on 256 CUs for 4.02 rounds of work (tools/pp_timeline.py: kernel span = 5 tile times).  The rows of the
+// short last round are cut off, their tiles K-split S ways in ONE launch (grid.y = slice: S CUs per tile, fp32 partial slabs), and
+// a reduce + epilogue launch sums the slabs into an LDS tile and drains it with the GEMMs' own epilogue code.
+__global__ __launch_bounds__(512) void gemm_ksplit_reduce_kernel(const float* __restrict__ part, long long slice_stride, int S, int R, int N,
+                                                                 GemmEpi e, int m_base, int M) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PITCH = PPN * 4 + 16;
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * 128, n0 = blockIdx.y * PPN;
+  const int c4 = tid & 63;                                     // 64 float4 columns of the 256-column tile
+  for (int rl = tid >> 6; rl < 128; rl += 8) {
+    const int r = r0 + rl, n = n0 + 4 * c4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < R && n < N) {
+      const float* p = part + (size_t)r * N + n;
+      for (int sl = 0; sl < S; ++sl) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)sl * slice_stride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(smem + rl * PITCH + c4 * 16) = acc;
+  }
+  __syncthreads();
+  const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
+  if (drain8_ok(e, N)) drain_tile_bf16x8<128, PPN, 512>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m_base + r0 + row_l; });
+  else drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m_base + r0 + row_l; });
+}
+
+static float* g_tail_scratch[16] = {};
+static size_t g_tail_bytes[16] = {};
+int gemm_tail_reserve(size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 3;
+  if (g_tail_bytes[dev] >= bytes) return 0;
+  if (g_tail_scratch[dev]) (void)hipFree(g_tail_scratch[dev]);
+  g_tail_scratch[dev] = nullptr; g_tail_bytes[dev] = 0;
+  if (hipMalloc((void**)&g_tail_scratch[dev], bytes) != hipSuccess) return 3;
+  g_tail_bytes[dev] = bytes;
+  return 0;
+}
+
+static thread_local bool t_in_tail_split = false;
+static long g_tail_splits = 0;
+extern "C" long dod_debug_tail_splits() { return g_tail_splits; }   // tuning / tests: how many GEMM calls took the split path
+int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+  if (t_in_tail_split || e.ksplit > 1 || e.rows_per_img != 0 || e.a_scale || e.out_split > 0) return -1;
+  static const char* off = getenv("DINODET_GEMM_TAILSPLIT");
+  if (off && off[0] == '0') return -1;
+  const int ktile = kind == 0 ? 64 : 32;
+  if (M < 8192 || N % 4 != 0 || K % ktile != 0) return -1;
+  // measured at M = 87680 (343 x 3 tiles, 4.02 rounds; tools/bench_h2.py, tools/bench_pp.py with DINODET_GEMM_TAILSPLIT=0 / 1): the unsplit
+  // kernels last 4.3 tile times, not 5 -- the five tiles of the last round run alone on the chip -- so the split pays only where a tile
+  // is long: split-product fc2 (K = 3072) 985 vs 1043 us, H2 fc2 909 vs 935; out-proj (K = 768) loses 7-11 % in every mode and the plain
+  // bf16 fc2 2 %.  Enabled for the compensated kernels at K >= 2048 (DINODET_GEMM_TAILSPLIT=2 forces it wherever the shape qualifies).
+  if (!(off && off[0] == '2') && (kind == 0 || K < 2048)) return -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
+  static int cus[16] = {};
+  if (!cus[dev]) { int c = 0; (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); cus[dev] = c > 0 ? c : 256; }
+  const int CU = cus[dev];
+  const int tiles_n = (N + PPN - 1) / PPN, tiles_m = (M + PPM - 1) / PPM, tiles = tiles_m * tiles_n;
+  const int rounds = tiles / CU, rem = tiles % CU;
+  if (rounds < 2 || rounds > 6 || rem == 0 || rem > CU / 8) return -1;     // a short last round that costs >= 1/7 of the kernel
+  const int m_main = (rounds * CU) / tiles_n;
+  const int Mmain = m_main * PPM, R = M - Mmain;
+  if (R <= 0 || R > 1024) return -1;
+  const int tiles_r = ((R + PPM - 1) / PPM) * tiles_n;
+  const int nk = K / ktile;
+  int S = 0;
+  for (int c : {8, 6, 4, 3, 2})
+    if (nk % c == 0 && nk / c >= 3 && tiles_r * c <= CU) { S = c; break; }
+  if (S < 2) return -1;
+  const size_t slab = (size_t)R * N;
+  if (g_tail_bytes[dev] < slab * S * 4 || !g_tail_scratch[dev]) return -1;           // reserved outside stream capture (gemm_tail_reserve)
+  float* scratch = g_tail_scratch[dev];
+  // ---- main rows: the caller's own dispatch
+  t_in_tail_split = true;
+  int rc;
+  if (kind == 0) rc = launch_gemm_bf16((const bf16_t*)A, lda, (const bf16_t*)W, ldw, Mmain, N, K, e, s);
+  else if (kind == 1) rc = launch_gemm_x3((const bf16_t*)A, lda, (const bf16_t*)W, ldw, Mmain, N, K, e, s);
+  else rc = launch_gemm_h2(A, lda, W, ldw, Mmain, N, K, e, s);
+  t_in_tail_split = false;
+  if (rc) return rc;
+  // ---- remainder rows, K-split: fp32 partial slabs
+  GemmEpi es; memset(&es, 0, sizeof es);
+  es.out_f32 = scratch; es.ldc = N; es.h2_wexp = e.h2_wexp;
+  es.ksplit = S; es.kslice_len = K / S; es.kslice_stride = (long long)slab;
+  const int gm = gemm_tile_mode() & 0xfff;          // no start stagger
+  if (kind == 2) {
+    constexpr int LDSH2 = (128 * (PPN * 4 + 16)) > H2_LDS ? (128 * (PPN * 4 + 16)) : H2_LDS;
+    static bool a2[16] = {};
+    if (!a2[dev]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSH2); a2[dev] = true; }
+    const char* Ar = (const char*)A + (size_t)Mmain * lda;
+    hipLaunchKernelGGL(gemm_h2_256x256_kernel, dim3(tiles_r, S), dim3(512), LDSH2, s, Ar, lda, (const char*)W, ldw, R, N, K, es, gm);
+  } else {
+    ppm_attr();
+    const bf16_t* Ar = (const bf16_t*)A + (size_t)Mmain * lda;
+    if (kind == 1) hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, false>), dim3(tiles_r, S), dim3(512), LDSPP, s, Ar, lda, (const bf16_t*)W, ldw, R, N, K, es, gm);
+    else hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, false>), dim3(tiles_r, S), dim3(512), LDSPP, s, Ar, lda, (const bf16_t*)W, ldw, R, N, K, es, gm);
+  }
+  if (hipGetLastError() != hipSuccess) return 3;
+  // ---- reduce + the caller's epilogue on global rows Mmain..M-1
+  static bool a3[16] = {};
+  constexpr int LDSR = 128 * (PPN * 4 + 16);
+  if (!a3[dev]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ksplit_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSR); a3[dev] = true; }
+  ++g_tail_splits;
+  hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3((R + 127) / 128, tiles_n), dim3(512), LDSR, s, scratch, (long long)slab, S, R, N, e, Mmain, M);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

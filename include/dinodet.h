@@ -307,6 +307,10 @@ int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_pa
 /* Tuning aid: when dev_buf is non-NULL the large bf16 GEMM kernel stores 4 x uint64 per workgroup
  * {realtime at start, after the K loop, at exit, blockIdx} (100 MHz s_memrealtime); NULL switches it off.
  * Used by tools/gemm_timeline.py. */
+/* Scratch of the GEMMs' wave-quantisation tail split (K-split partial slabs; gemm_pp.hip).  dod_finalize_weights reserves 64 MiB on the
+ * current device; operator-level callers (tests, tools) reserve it themselves.  Never allocated inside a forward / stream capture. */
+int dod_reserve_gemm_scratch(size_t bytes);
+long dod_debug_tail_splits(void);   /* number of GEMM calls that took the tail-split path so far (tests) */
 int dod_debug_gemm_stamps(void* dev_buf);
 /* same for the ping-pong kernels (gemm_pp.hip): 8 x uint64 per workgroup, shader cycles (tools/pp_timeline.py) */
 int dod_debug_pp_stamps(void* dev_buf);

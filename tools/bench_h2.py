@@ -5,7 +5,7 @@ import os, statistics, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from dinov2_od_amd import _native as nat
-L = nat.lib(); dev = torch.device("cuda:0")
+L = nat.lib(); L.dod_reserve_gemm_scratch(64 << 20); dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 B = int(os.environ.get("X3_B", "64")); D = 768; M = int(os.environ.get("X3_ROWS", B * 1370))
 def pair(x):

@@ -5,7 +5,7 @@ import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from dinov2_od_amd import _native as nat
-L = nat.lib(); dev = torch.device("cuda:0")
+L = nat.lib(); L.dod_reserve_gemm_scratch(64 << 20); dev = torch.device("cuda:0")
 X3 = os.environ.get("X3", "1") == "1"
 if X3: os.environ["DINODET_X3_TILE"] = os.environ.get("PP_VARIANT", "p")
 else: os.environ["DINODET_GEMM_TILE"] = os.environ.get("PP_VARIANT", "q")
