@@ -775,8 +775,31 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   // (also at small grids: at M = 10960 -- batch 8 -- QKV 730 vs 639, out-proj 396 vs 375, fc2 634 vs 526 TFLOP/s)
   if (force && force[0] == 'p' && K % 64 == 0) return launch_gemm_bf16_pp(A, lda, W, ldw, M, N, K, e, s);
   if (force && (force[0] == 'q' || force[0] == 'r') && K % 64 == 0) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
-  if (force ? force[0] == 'x' : (M >= 4096 && N >= 512 && e.act != ACT_GELU && e.act != ACT_SIGMOID && e.rows_per_img == 0))
-    return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
+  if (force && force[0] == 'x') return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
+  if (!force && M >= 4096 && N >= 512 && K % 64 == 0 && e.act != ACT_SIGMOID && e.rows_per_img == 0) {
+    // Round-aware choice between the 256x256 tiles (one workgroup per CU: `k64`, or the 8-wave ping-pong kernel, which is 3-7 % faster
+    // on N >= 1536 at every M measured) and the 256x128 tile (`m16`, two co-resident workgroups per CU that run at about half speed
+    // each, so one of its tiles costs ~0.55 of a 256x256 tile only while a CU holds a single one).  Cost in units of a 256x256 tile
+    // time = rounds of CUs x tile cost; a GELU epilogue costs the one-workgroup-per-CU kernels ~8 % (nothing overlaps it).
+    // tools/bench_pp.py --rows {4112, 8224, 16448, 21920, 43840, 87680}: the rule reproduces the faster kernel in 23 of 24 cases
+    // (M = 8224, batch 32 at 224x224: QKV 46 vs 53 us, out-proj 27 vs 32, fc1 66 vs 78, fc2 59 vs 75).
+    static int cus = 0;
+    if (!cus) { int dev = 0, c = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); cus = c > 0 ? c : 256; }
+    const long tm = (M + 255) / 256, t_big = tm * ((N + 255) / 256), t_small = tm * ((N + 127) / 128);
+    const double c_big = (double)((t_big + cus - 1) / cus) * (e.act == ACT_GELU ? 1.08 : 1.0);
+    const double c_small = (double)((t_small + cus - 1) / cus) * (K >= 2048 ? 0.62 : 0.55);      // long K: the smaller tile's lower FLOP per staged byte shows
+    if (c_big <= c_small * 1.02) {
+      if (N >= 1536) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
+      return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
+    }
+    {
+      static const char* gme = getenv("DINODET_GEMM_GM");
+      const int gm = (gme ? (atoi(gme) & 0xff) : (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2))) | (gemm_tile_mode() & 0x300);
+      const int tiles = ((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
+      hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e, gm);
+      return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
+  }
   // shape heuristic (measured on MI355X, tools/bench_gemm_k.py / bench_ops.py at M = 87680, random data):
   //   256x128x32 with v_mfma_f32_16x16x32_bf16, two workgroups per CU: QKV 703, out-proj 437, fc1 646, fc2 643 TFLOP/s
   //   same tile with 32x32x16: 651 / 405 / 607 / 621;  256x256 (one per CU): 624 / 342 / 554 / 619-643
