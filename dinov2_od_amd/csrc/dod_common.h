@@ -183,6 +183,8 @@ int launch_split2(const float* in, int ld_in, bf16_t* out, int rows, int K, hipS
 int launch_split_h2(const float* in, int ld_in, void* out, int rows, int K, unsigned char* wexp, hipStream_t s);
 // H2 GEMM (gemm_pp.hip): A [M, K] activation rows (pitch lda BYTES >= 4K), W [N, K] weight rows (pitch ldw BYTES >= 3K), e.h2_wexp set
 int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
+// fp8 GEMM on the 8-wave ping-pong skeleton (gemm_pp.hip): K % 128 == 0; launch_gemm_fp8 routes the large shapes here
+int launch_gemm_fp8_pp(const unsigned char* A, int lda, const unsigned char* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 // Wave-quantisation tail of the 256x256-tile GEMMs (gemm_pp.hip): when tiles % CUs leaves a short last round (1029 tiles on 256
 // CUs: a fifth round for five tiles, +24 %), the rows of that round are cut off the main launch and computed by a K-SPLIT launch
 // (every tile of the remainder as S slices on S CUs, fp32 partials to a scratch buffer) plus a reduce + epilogue launch.

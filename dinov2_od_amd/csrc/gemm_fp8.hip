@@ -143,6 +143,18 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
   if (!e.a_scale || !e.w_scale) return 2;
+  {
+    // the 256x256 ping-pong kernel (gemm_pp.hip) where the K loop is long enough to pay for its one-workgroup-per-CU prologue /
+    // epilogue; measured (tools/bench_fp8.py, DINODET_FP8_TILE = p / o forces either kernel): ViT-g, 32 x 518^2: QKV (K 1536) 449 vs
+    // 474 us, MLP-in (K 1536) 769 vs 772, MLP-out (K 4096) 318 vs 381 (1 733 TFLOP/s); at K = 768 (ViT-B QKV / fc1) it loses 11 %.
+    // In the ViT-g forward, forced onto every linear, it LOSES (fp8 GEMM class 75.2 vs 64.3 ms): with K loops this short the in-place fp32
+    // residual epilogue of out-proj / MLP-out (63 k cycles on a one-workgroup-per-CU kernel) outweighs the loop ; restricted to
+    // the QKV / MLP-in linears it still loses (68.8 vs 63.5 ms: in the forward their operands arrive from the producing kernels, not
+    // from a warm cache).  Kept as an opt-in (DINODET_FP8_TILE=p); the two-workgroups-per-CU kernel below stays the default
+    static const char* v = getenv("DINODET_FP8_TILE");
+    const bool pp = v && v[0] == 'p';      // opt-in only: see above
+    if (pp && K % 128 == 0) return launch_gemm_fp8_pp(A, lda, W, ldw, M, N, K, e, s);
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);

@@ -598,6 +598,146 @@ __global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) GEMM on the same 8-wave ping-pong skeleton (the ViT-g/14 fp8 configuration, BASELINE configs[4]; replaces the
+// 256x128 two-workgroups-per-CU kernel of gemm_fp8.hip on the large shapes): K-tile = 128 k as four planes of [256 rows][64 B]
+// (A k0..63 | A k64..127 | W k0..63 | W k64..127, two 64-KiB buffers), 32x32 lane map as in the H2 kernel (lane (r, g) reads chunks
+// 2g, 2g+1 of a plane row = one v_mfma_f32_32x32x64_f8f6f4 operand; scale operands constant 0 -> the unscaled form), two phases per
+// K-tile (row blocks 2p, 2p+1: 8 MFMAs = 512 matrix-pipe cycles per COMPUTE segment), dequantisation a_scale[m] w_scale[n] in the
+// shared epilogue.  Per staged byte it needs the matrix-pipe cycles of the plain bf16 ping-pong kernel -- i.e. it runs into the
+// same per-CU global->LDS path -- at twice the FLOPs per byte.
+__global__ __launch_bounds__(512) void gemm_fp8pp_256x256_kernel(const char* __restrict__ A, int lda, const char* __restrict__ W, int ldw,
+                                                                 int M, int N, int K, GemmEpi e, int GM) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const int grp_ = wu >> 2, wq = wu & 3;
+  const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
+  int tm, tn;
+  tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
+  const int m0 = tm * PPM, n0 = tn * PPN;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  unsigned vA0, vA1, vW0, vW1;
+  {
+    const int rl = wid * 32 + (lane >> 2);
+    const int c = h2_swz(rl, lane & 3);
+    int ra0 = m0 + rl, ra1 = m0 + rl + 16; ra0 = ra0 < M ? ra0 : M - 1; ra1 = ra1 < M ? ra1 : M - 1;
+    int rw0 = n0 + rl, rw1 = n0 + rl + 16; rw0 = rw0 < N ? rw0 : N - 1; rw1 = rw1 < N ? rw1 : N - 1;
+    vA0 = (unsigned)((size_t)ra0 * lda + c * 16); vA1 = (unsigned)((size_t)ra1 * lda + c * 16);
+    vW0 = (unsigned)((size_t)rw0 * ldw + c * 16); vW1 = (unsigned)((size_t)rw1 * ldw + c * 16);
+  }
+  const size_t bytesA = (size_t)M * lda, bytesW = (size_t)N * ldw;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(bytesA > 0xfffffff0u ? 0xfffffff0u : bytesA), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)(bytesW > 0xfffffff0u ? 0xfffffff0u : bytesW), 0x00020000);
+  char* const sdst = smem + wu * 2048;
+  // plane pl (0: A k0..63, 1: A k64..127, 2: W k0..63, 3: W k64..127) of K-tile t -> buffer t & 1
+#define F8P_STAGE(t, pl)                                                                                       \
+  {                                                                                                            \
+    char* d_ = sdst + ((t) & 1) * PP_TILE + (pl) * PP_PLANE;                                                   \
+    const int ko_ = (t) * 128 + ((pl) & 1) * 64;                                                               \
+    if ((pl) < 2) {                                                                                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(d_), 16, vA0, ko_, 0, 0);                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(d_ + 1024), 16, vA1, ko_, 0, 0);                   \
+    } else {                                                                                                   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(d_), 16, vW0, ko_, 0, 0);                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(d_ + 1024), 16, vW1, ko_, 0, 0);                   \
+    }                                                                                                          \
+  }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = K / 128;
+  const int lr = lane & 31, lg = lane >> 5;
+  int offA[4], offW[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int row = grp_ * 128 + i * 32 + lr; offA[i] = row * 64 + h2_swz(row, 2 * lg) * 16; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int row = wq * 64 + j * 32 + lr; offW[j] = 2 * PP_PLANE + row * 64 + h2_swz(row, 2 * lg) * 16; }
+
+  F8P_STAGE(0, 0) F8P_STAGE(0, 1) F8P_STAGE(0, 2) F8P_STAGE(0, 3)
+  if (nk > 1) { F8P_STAGE(1, 2) F8P_STAGE(1, 3) }
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp_ == 1) __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 wf[2][2][2], af[2][2][2];       // [block][plane][chunk], read as ushort vectors (an int-typed read would make hipcc drain the DMA ring)
+  // PF: 0 none, 1 the two A planes of K-tile PF_T, 2 the two W planes of K-tile PF_T; VW: vmcnt at the end of the LOAD segment (-1 none)
+#define F8P_PHASE(st, p, PF, PF_T, VW)                                                                         \
+  {                                                                                                            \
+    if ((p) == 0) {                                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+        _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                     \
+          wf[j][pl][0] = *reinterpret_cast<const bf16x8*>((st) + offW[j] + pl * PP_PLANE);                     \
+          wf[j][pl][1] = *reinterpret_cast<const bf16x8*>((st) + (offW[j] ^ 16) + pl * PP_PLANE);              \
+        }                                                                                                      \
+    }                                                                                                          \
+    _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                           \
+      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                       \
+        af[ii][pl][0] = *reinterpret_cast<const bf16x8*>((st) + offA[2 * (p) + ii] + pl * PP_PLANE);           \
+        af[ii][pl][1] = *reinterpret_cast<const bf16x8*>((st) + (offA[2 * (p) + ii] ^ 16) + pl * PP_PLANE);    \
+      }                                                                                                        \
+    if ((PF) == 1) { F8P_STAGE(PF_T, 0) F8P_STAGE(PF_T, 1) }                                                   \
+    if ((PF) == 2) { F8P_STAGE(PF_T, 2) F8P_STAGE(PF_T, 3) }                                                   \
+    if ((VW) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
+    else if ((VW) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                           \
+      _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                       \
+        const i32x8_ av = __builtin_shufflevector(__builtin_bit_cast(i32x4_, af[ii][pl][0]), __builtin_bit_cast(i32x4_, af[ii][pl][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+          const i32x8_ wv = __builtin_shufflevector(__builtin_bit_cast(i32x4_, wf[j][pl][0]), __builtin_bit_cast(i32x4_, wf[j][pl][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
+          acc[2 * (p) + ii][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, acc[2 * (p) + ii][j], 0, 0, 0, 0, 0, 0); \
+        }                                                                                                      \
+      }                                                                                                        \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  }
+
+  int u = 0;
+  for (; u + 2 < nk; ++u) {
+    const char* st = smem + (u & 1) * PP_TILE;
+    F8P_PHASE(st, 0, 1, u + 1, -1)
+    F8P_PHASE(st, 1, 2, u + 2, 4)               // tile u + 1 complete; the two W planes of u + 2 in flight
+  }
+  if (u + 1 < nk) {
+    const char* st = smem + (u & 1) * PP_TILE;
+    F8P_PHASE(st, 0, 1, u + 1, -1)
+    F8P_PHASE(st, 1, 0, 0, 0)
+    ++u;
+  }
+  {
+    const char* st = smem + (u & 1) * PP_TILE;
+    F8P_PHASE(st, 0, 0, 0, -1)
+    F8P_PHASE(st, 1, 0, 0, -1)
+  }
+  if (grp_ == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  constexpr int PITCH = PPN * 4 + 16;
+  const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) stage_acc(smem, PITCH, grp_ * 64 + ii * 32 + lr, wq * 64 + j * 32, acc[pass * 2 + ii][j], lg);
+    __syncthreads();
+    drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+  }
+}
+
 static constexpr int LDSPP = (128 * (PPN * 4 + 16)) > 2 * PP_TILE ? (128 * (PPN * 4 + 16)) : 2 * PP_TILE;
 
 // K % 64 == 0, K >= 64
@@ -799,5 +939,21 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   if (!a3[dev]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ksplit_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSR); a3[dev] = true; }
   ++g_tail_splits;
   hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3((R + 127) / 128, tiles_n), dim3(512), LDSR, s, scratch, (long long)slab, S, R, N, e, Mmain, M);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// fp8 (e4m3) operands, one byte per element, row pitches lda / ldw bytes; K % 128 == 0; e.a_scale / e.w_scale set
+int launch_gemm_fp8_pp(const unsigned char* A, int lda, const unsigned char* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 128 != 0) return 2;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8pp_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
+    attr_set[dev] = true;
+  }
+  const int gm = gemm_tile_mode();
+  const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
+  hipLaunchKernelGGL(gemm_fp8pp_256x256_kernel, dim3(tiles), dim3(512), LDSPP, s, (const char*)A, lda, (const char*)W, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
