@@ -156,7 +156,7 @@ __device__ unsigned long long* g_attn_stamps = nullptr;
 
 template <int AT_NQ>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                        int N, int heads, int npairs, float scale_log2e) {
+                                                        int N, int heads, int npairs, float scale_log2e, int q_lo, int q_hi) {
   __shared__ __attribute__((aligned(16))) char smem[3 * 2 * AT_KV * 128];   // [slot][K|V][64 rows][128 B] = 48 KiB
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
   // there; with the plain (q-block, head, image) grid each XCD saw ~70 different pairs at once (24 MB of K/V
   // against a 4 MB L2: FETCH_SIZE showed K/V fetched 5.5x).  Speed only; any placement is correct.
   constexpr int AT_QW = 32 * AT_NQ;
-  const int nqb = (N + AT_WAVES * AT_QW - 1) / (AT_WAVES * AT_QW);
+  const int nqb = (q_hi - q_lo + AT_WAVES * AT_QW - 1) / (AT_WAVES * AT_QW);      // query rows [q_lo, q_hi) of every (image, head); keys 0..N-1
   int b, h, qb;
   {
     const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
     b = pair / heads;
     h = pair - b * heads;
   }
-  const int q0 = qb * (AT_WAVES * AT_QW) + wid * AT_QW;
+  const int q0 = q_lo + qb * (AT_WAVES * AT_QW) + wid * AT_QW;
   const bf16_t* base = qkv + (size_t)b * N * ld;
 
   // Q fragments: B operand of S^T = K Q^T: lane holds Q[q = lr][d = 16 t + 8 lh + 0..7]
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
     for (int r = 0; r < 16; ++r) { o[q][0][r] = 0.f; o[q][1][r] = 0.f; }
     m_run[q] = -INFINITY; l_run[q] = 0.f;
   }
-  const bool active = __builtin_amdgcn_readfirstlane(q0) < N;     // waves past the last row only stage and sync
+  const bool active = __builtin_amdgcn_readfirstlane(q0) < q_hi;     // waves past the last row only stage and sync
 
   // tr-read lane geometry (ds_read_b64_tr_b16: 16-lane groups, lane 4q+p supplies row q, cols 4p..4p+3)
   const int g16 = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
     const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0 + qi * 32 + lr;
-    if (active && q < N) {
+    if (active && q < q_hi) {
       bf16_t* op = ctx + ((size_t)b * N + q) * D + h * 64;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -301,11 +301,19 @@ int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, fl
   // -12 % at 96), else 32
   static const char* nqe = getenv("DINODET_ATTN_NQ");   // tuning override
   if (nqe ? nqe[0] == '2' : (long)npairs * ((N + 255) / 256) >= 4 * 256) {
-    const int nqb = (N + AT_WAVES * 64 - 1) / (AT_WAVES * 64);
-    hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c);
+    // A workgroup lasts as long as its busiest wave: the last 256-row block of N = 1370 (90 rows) keeps one wave fully busy and costs a
+    // whole block time for a third of the rows.  When the remainder fits 128 rows it goes to a second launch of the 32-rows-per-wave
+    // kernel (three waves with one q-block each: about half a block time): 5 + 0.55 instead of 6 block times per (image, head).
+    const int rem = N % (AT_WAVES * 64);
+    static const char* tse = getenv("DINODET_ATTN_TAILSPLIT");
+    const bool split = (tse ? tse[0] != '0' : true) && rem > 0 && rem <= AT_WAVES * 32 && N > AT_WAVES * 64;
+    const int q_main = split ? N - rem : N;
+    const int nqb = (q_main + AT_WAVES * 64 - 1) / (AT_WAVES * 64);
+    hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, 0, q_main);
+    if (split) hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, q_main, N);
   } else {
     const int nqb = (N + AT_WAVES * 32 - 1) / (AT_WAVES * 32);
-    hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c);
+    hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, 0, N);
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
