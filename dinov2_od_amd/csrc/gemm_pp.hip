@@ -835,14 +835,16 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
 // M = 87680 take FIVE rounds on 256 CUs for 4.02 rounds of work (tools/pp_timeline.py: kernel span = 5 tile times).  The rows of the
 // short last round are cut off, their tiles K-split S ways in ONE launch (grid.y = slice: S CUs per tile, fp32 partial slabs), and
 // a reduce + epilogue launch sums the slabs into an LDS tile and drains it with the GEMMs' own epilogue code.
+#define KSR_ROWS 16      // rows per workgroup of the reduce launch: 16 x 256 outputs, so that a 384-row remainder still spreads over 72 CUs
 __global__ __launch_bounds__(512) void gemm_ksplit_reduce_kernel(const float* __restrict__ part, long long slice_stride, int S, int R, int N,
                                                                  GemmEpi e, int m_base, int M) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ __attribute__((aligned(16))) char smem[KSR_ROWS * (PPN * 4 + 16)];
   constexpr int PITCH = PPN * 4 + 16;
   const int tid = threadIdx.x;
-  const int r0 = blockIdx.x * 128, n0 = blockIdx.y * PPN;
+  const int r0 = blockIdx.x * KSR_ROWS, n0 = blockIdx.y * PPN;
   const int c4 = tid & 63;                                     // 64 float4 columns of the 256-column tile
-  for (int rl = tid >> 6; rl < 128; rl += 8) {
+#pragma unroll
+  for (int rl = tid >> 6; rl < KSR_ROWS; rl += 8) {
     const int r = r0 + rl, n = n0 + 4 * c4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < R && n < N) {
@@ -856,8 +858,8 @@ __global__ __launch_bounds__(512) void gemm_ksplit_reduce_kernel(const float* __
   }
   __syncthreads();
   const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
-  if (drain8_ok(e, N)) drain_tile_bf16x8<128, PPN, 512>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m_base + r0 + row_l; });
-  else drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m_base + r0 + row_l; });
+  if (drain8_ok(e, N)) drain_tile_bf16x8<KSR_ROWS, PPN, 512>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m_base + r0 + row_l; });
+  else drain_tile<KSR_ROWS, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m_base + r0 + row_l; });
 }
 
 static float* g_tail_scratch[16] = {};
@@ -882,11 +884,11 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   if (off && off[0] == '0') return -1;
   const int ktile = kind == 0 ? 64 : 32;
   if (M < 8192 || N % 4 != 0 || K % ktile != 0) return -1;
-  // measured at M = 87680 (343 x 3 tiles, 4.02 rounds; tools/bench_h2.py, tools/bench_pp.py with DINODET_GEMM_TAILSPLIT=0 / 1): the unsplit
-  // kernels last 4.3 tile times, not 5 -- the five tiles of the last round run alone on the chip -- so the split pays only where a tile
-  // is long: split-product fc2 (K = 3072) 985 vs 1043 us, H2 fc2 909 vs 935; out-proj (K = 768) loses 7-11 % in every mode and the plain
-  // bf16 fc2 2 %.  Enabled for the compensated kernels at K >= 2048 (DINODET_GEMM_TAILSPLIT=2 forces it wherever the shape qualifies).
-  if (!(off && off[0] == '2') && (kind == 0 || K < 2048)) return -1;
+  // measured at M = 87680 (343 x 3 tiles, 4.02 rounds; tools/bench_h2.py, tools/bench_pp.py with DINODET_GEMM_TAILSPLIT=0 / 2): the unsplit
+  // kernels last ~4.3 tile times, not 5 -- the five tiles of the last round run alone on the chip -- so the split pays where a tile is
+  // long: fc2 (K = 3072) 976 vs 1047 us (split product), 866 vs 944 (H2), 474 vs 491 (plain bf16); out-proj (K = 768) 367 vs 373, 346
+  // vs 350, 218 vs 217: not worth a second and third launch.  Enabled at K >= 2048 (DINODET_GEMM_TAILSPLIT=2 forces every qualifying shape).
+  if (!(off && off[0] == '2') && K < 2048) return -1;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
   static int cus[16] = {};
@@ -934,11 +936,8 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   }
   if (hipGetLastError() != hipSuccess) return 3;
   // ---- reduce + the caller's epilogue on global rows Mmain..M-1
-  static bool a3[16] = {};
-  constexpr int LDSR = 128 * (PPN * 4 + 16);
-  if (!a3[dev]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ksplit_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSR); a3[dev] = true; }
   ++g_tail_splits;
-  hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3((R + 127) / 128, tiles_n), dim3(512), LDSR, s, scratch, (long long)slab, S, R, N, e, Mmain, M);
+  hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3((R + KSR_ROWS - 1) / KSR_ROWS, tiles_n), dim3(512), 0, s, scratch, (long long)slab, S, R, N, e, Mmain, M);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
