@@ -776,6 +776,10 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   if (force && force[0] == 'p' && K % 64 == 0) return launch_gemm_bf16_pp(A, lda, W, ldw, M, N, K, e, s);
   if (force && (force[0] == 'q' || force[0] == 'r') && K % 64 == 0) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
   if (force && force[0] == 'x') return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
+  static const char* rule_env = getenv("DINODET_GEMM_RULE");     // "0": the round-1 heuristic below (A/B)
+  if (rule_env && rule_env[0] == '0') {
+    if (!force && M >= 4096 && N >= 512 && e.act != ACT_GELU && e.act != ACT_SIGMOID && e.rows_per_img == 0) return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
+  } else
   if (!force && M >= 4096 && N >= 512 && K % 64 == 0 && e.act != ACT_SIGMOID && e.rows_per_img == 0) {
     // Round-aware choice between the 256x256 tiles (one workgroup per CU: `k64`, or the 8-wave ping-pong kernel, which is 3-7 % faster
     // on N >= 1536 at every M measured) and the 256x128 tile (`m16`, two co-resident workgroups per CU that run at about half speed

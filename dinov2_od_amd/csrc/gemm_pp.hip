@@ -883,40 +883,52 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   static const char* off = getenv("DINODET_GEMM_TAILSPLIT");
   if (off && off[0] == '0') return -1;
   const int ktile = kind == 0 ? 64 : 32;
-  if (M < 8192 || N % 4 != 0 || K % ktile != 0) return -1;
-  // measured at M = 87680 (343 x 3 tiles, 4.02 rounds; tools/bench_h2.py, tools/bench_pp.py with DINODET_GEMM_TAILSPLIT=0 / 2): the unsplit
-  // kernels last ~4.3 tile times, not 5 -- the five tiles of the last round run alone on the chip -- so the split pays where a tile is
-  // long: fc2 (K = 3072) 976 vs 1047 us (split product), 866 vs 944 (H2), 474 vs 491 (plain bf16); out-proj (K = 768) 367 vs 373, 346
-  // vs 350, 218 vs 217: not worth a second and third launch.  Enabled at K >= 2048 (DINODET_GEMM_TAILSPLIT=2 forces every qualifying shape).
-  if (!(off && off[0] == '2') && K < 2048) return -1;
+  if (N % 4 != 0 || K % ktile != 0) return -1;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
   static int cus[16] = {};
   if (!cus[dev]) { int c = 0; (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); cus[dev] = c > 0 ? c : 256; }
   const int CU = cus[dev];
   const int tiles_n = (N + PPN - 1) / PPN, tiles_m = (M + PPM - 1) / PPM, tiles = tiles_m * tiles_n;
-  const int rounds = tiles / CU, rem = tiles % CU;
-  if (rounds < 2 || rounds > 6 || rem == 0 || rem > CU / 8) return -1;     // a short last round that costs >= 1/7 of the kernel
-  const int m_main = (rounds * CU) / tiles_n;
-  const int Mmain = m_main * PPM, R = M - Mmain;
-  if (R <= 0 || R > 1024) return -1;
-  const int tiles_r = ((R + PPM - 1) / PPM) * tiles_n;
   const int nk = K / ktile;
-  int S = 0;
-  for (int c : {8, 6, 4, 3, 2})
-    if (nk % c == 0 && nk / c >= 3 && tiles_r * c <= CU) { S = c; break; }
+  const bool force = off && off[0] == '2';
+  int Mmain, R, tiles_r, S = 0;
+  if (kind >= 1 && M >= 2048 && tiles * 2 <= CU + CU / 8) {
+    // (a) an UNDERFILLED single round (the compensated kernels have no smaller tile): 99 tiles of an N = 768 GEMM at M = 8224 leave 157
+    // CUs idle -- every tile is K-split so that tiles x S fills the chip (no main launch)
+    Mmain = 0; R = M; tiles_r = tiles;
+    for (int c : {8, 6, 4, 3, 2})
+      if (nk % c == 0 && nk / c >= 3 && tiles_r * c <= CU) { S = c; break; }
+  } else {
+    // (b) a short LAST round.  Measured at M = 87680 (343 x 3 tiles, 4.02 rounds; tools/bench_h2.py, tools/bench_pp.py with
+    // DINODET_GEMM_TAILSPLIT=0 / 2): the unsplit kernels last ~4.3 tile times, not 5 -- the five tiles of the last round run alone on
+    // the chip -- so the split pays where a tile is long: fc2 (K = 3072) 976 vs 1047 us (split product), 866 vs 944 (H2), 474 vs 491
+    // (plain bf16); out-proj (K = 768) 367 vs 373, 346 vs 350, 218 vs 217: not worth a second and third launch.  Enabled at K >= 2048
+    // (DINODET_GEMM_TAILSPLIT=2 forces every qualifying shape).
+    if (M < 8192 || (!force && K < 2048)) return -1;
+    const int rounds = tiles / CU, rem = tiles % CU;
+    if (rounds < 2 || rounds > 6 || rem == 0 || rem > CU / 8) return -1;     // a short last round that costs >= 1/7 of the kernel
+    const int m_main = (rounds * CU) / tiles_n;
+    Mmain = m_main * PPM; R = M - Mmain;
+    if (R <= 0 || R > 1024) return -1;
+    tiles_r = ((R + PPM - 1) / PPM) * tiles_n;
+    for (int c : {8, 6, 4, 3, 2})
+      if (nk % c == 0 && nk / c >= 3 && tiles_r * c <= CU) { S = c; break; }
+  }
   if (S < 2) return -1;
   const size_t slab = (size_t)R * N;
   if (g_tail_bytes[dev] < slab * S * 4 || !g_tail_scratch[dev]) return -1;           // reserved outside stream capture (gemm_tail_reserve)
   float* scratch = g_tail_scratch[dev];
   // ---- main rows: the caller's own dispatch
-  t_in_tail_split = true;
-  int rc;
-  if (kind == 0) rc = launch_gemm_bf16((const bf16_t*)A, lda, (const bf16_t*)W, ldw, Mmain, N, K, e, s);
-  else if (kind == 1) rc = launch_gemm_x3((const bf16_t*)A, lda, (const bf16_t*)W, ldw, Mmain, N, K, e, s);
-  else rc = launch_gemm_h2(A, lda, W, ldw, Mmain, N, K, e, s);
-  t_in_tail_split = false;
-  if (rc) return rc;
+  if (Mmain > 0) {
+    t_in_tail_split = true;
+    int rc;
+    if (kind == 0) rc = launch_gemm_bf16((const bf16_t*)A, lda, (const bf16_t*)W, ldw, Mmain, N, K, e, s);
+    else if (kind == 1) rc = launch_gemm_x3((const bf16_t*)A, lda, (const bf16_t*)W, ldw, Mmain, N, K, e, s);
+    else rc = launch_gemm_h2(A, lda, W, ldw, Mmain, N, K, e, s);
+    t_in_tail_split = false;
+    if (rc) return rc;
+  }
   // ---- remainder rows, K-split: fp32 partial slabs
   GemmEpi es; memset(&es, 0, sizeof es);
   es.out_f32 = scratch; es.ldc = N; es.h2_wexp = e.h2_wexp;

@@ -1,6 +1,7 @@
-"""Wave-quantisation tail split of the 256x256-tile GEMMs (gemm_pp.hip gemm_tail_split): a shape whose tile count leaves a short last
-round (513 tiles on 256 CUs) takes the main launch + K-split remainder + reduce path; results against fp64, every epilogue that the
-forward uses on these GEMMs (in-place fp32 residual with LayerScale; bf16; bf16 pair; H2 rows with GELU)."""
+"""K-split paths of the 256x256-tile GEMMs (gemm_pp.hip gemm_tail_split): (a) a shape whose tile count leaves a short last round (516
+tiles on 256 CUs) takes the main launch + K-split remainder + reduce path; (b) an underfilled single round (99 tiles: the
+compensated kernels have no smaller tile) is K-split whole.  Results against fp64, every epilogue that the forward uses on these
+GEMMs (in-place fp32 residual with LayerScale; bf16; bf16 pair; H2 rows with GELU)."""
 import numpy as np
 import pytest
 import torch
@@ -14,18 +15,22 @@ from tests.test_gpu_x3 import _pair
 import os
 os.environ.setdefault("DINODET_GEMM_TAILSPLIT", "2")     # force the split path for every qualifying shape (read once per process, at the first GEMM)
 pytestmark = pytest.mark.gpu
-M, N, K = 171 * 256 + 40, 768, 768          # 172 x 3 = 516 tiles: two rounds of 256 + 4 -> rows 170*256.. are the remainder
+N, K = 768, 768
+M_TAIL = 171 * 256 + 40        # 172 x 3 = 516 tiles: two rounds of 256 + 4 -> rows 170*256.. are the remainder
+M_UNDER = 32 * 256 + 8         # 33 x 3 = 99 tiles: K-split two ways (compensated kernels; the plain bf16 GEMM has a 256x128 tile for this)
 
 
 def _n(tag, shape, std=1.0):
     return torch.from_numpy(synth.normal(13, tag, shape, std))
 
 
-@pytest.fixture(scope="module")
-def data():
+@pytest.fixture(scope="module", params=[M_TAIL, M_UNDER], ids=["tail", "underfilled"])
+def data(request):
+    global M
+    M = request.param
     nat.check(nat.lib().dod_reserve_gemm_scratch(64 << 20))
-    A, W = _n("ts.A", (M, K)), _n("ts.W", (N, K), 0.05)
-    bias, scale, resid = _n("ts.b", (N,)), 1 + _n("ts.s", (N,), 0.1), _n("ts.r", (M, N))
+    A, W = _n(f"ts.A.{M}", (M, K)), _n("ts.W", (N, K), 0.05)
+    bias, scale, resid = _n("ts.b", (N,)), 1 + _n("ts.s", (N,), 0.1), _n(f"ts.r.{M}", (M, N))
     dev = {"bias": bias.cuda(), "scale": scale.cuda()}        # device copies that outlive every launch below
     return A, W, bias, scale, resid, A.double() @ W.double().t(), dev
 
@@ -35,7 +40,7 @@ def _took_split(before):
 
 
 def _rows():
-    return slice(170 * 256 - 300, M)      # straddles the main / remainder cut
+    return slice(max(0, M - 600), M)      # straddles the main / remainder cut of the tail case
 
 
 def test_tail_split_plain_bf16(data):
@@ -51,7 +56,7 @@ def test_tail_split_plain_bf16(data):
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     nat.check(L.dod_op_linear(1, nat.ptr(Ab), K, nat.ptr(Wb), K, M, N, K, nat.ptr(dev["bias"]), None, None, 0, nat.ptr(out), 1, N, 0, nat.stream_ptr()))
     assert rel_err(out.float().cpu().numpy()[_rows()], (ref + bias.double()).numpy()[_rows()]) < 2 ** -8
-    assert _took_split(n0 + 1)
+    assert M == M_UNDER or _took_split(n0 + 1)
 
 
 def test_tail_split_x3(data):
