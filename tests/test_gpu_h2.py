@@ -98,3 +98,23 @@ def test_linear_h2_all_epilogues(M, N, K):
         assert rel_err(h.numpy(), want.numpy()) < 2 ** -11
         assert rel_err((h + r8).numpy(), want.numpy()) < 5e-5
         assert rel_err(m8.numpy(), want.numpy()) < 2 ** -3
+
+
+def test_linear_h2_outliers_degrade_gracefully():
+    """Activations beyond the e4m3 range (|x| > 448: the cross terms see them clamped) and beyond the fp16 range (clamped at 65504):
+    no NaN / inf; the error stays at the fp16-single-product level for the affected terms (the mode degrades, it does not overflow)."""
+    L = nat.lib()
+    M, N, K = 512, 256, 768
+    A, W = _n("h2.o.A", (M, K)), _n("h2.o.W", (N, K), 0.05)
+    A[::7, ::13] *= 900.0                       # up to ~3000: beyond e4m3, inside fp16
+    A[5, 17] = 1.0e5                            # beyond fp16: clamped to 65504 by the packer
+    Ab, _ = pack(A.cuda())
+    Wb, wexp = pack(W.cuda(), weight=True)
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    nat.check(L.dod_op_linear_h2(nat.ptr(Ab), nat.ptr(Wb), nat.ptr(wexp), M, N, K, None, None, None, 0, nat.ptr(out), 0, N, 0, nat.stream_ptr()))
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    exact = A.clamp(-65504, 65504).double() @ W.double().t()
+    assert rel_err(got.numpy(), exact.numpy()) < 1e-3       # 2^-11-class: the clamped entries' cross terms are lost, nothing else
+    rows = [r for r in range(M) if r % 7 != 0 and r != 5]   # rows without outliers keep the full accuracy
+    assert rel_err(got.numpy()[rows], exact.numpy()[rows]) < 5e-5
