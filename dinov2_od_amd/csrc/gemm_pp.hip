@@ -907,13 +907,16 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
     // (DINODET_GEMM_TAILSPLIT=2 forces every qualifying shape).
     if (M < 8192 || (!force && K < 2048)) return -1;
     const int rounds = tiles / CU, rem = tiles % CU;
-    if (rounds < 2 || rounds > 6 || rem == 0 || rem > CU / 8) return -1;     // a short last round that costs >= 1/7 of the kernel
+    if (rounds < 1 || rounds > 6 || rem == 0) return -1;
     const int m_main = (rounds * CU) / tiles_n;
     Mmain = m_main * PPM; R = M - Mmain;
-    if (R <= 0 || R > 1024) return -1;
+    if (R <= 0) return -1;
     tiles_r = ((R + PPM - 1) / PPM) * tiles_n;
     for (int c : {8, 6, 4, 3, 2})
       if (nk % c == 0 && nk / c >= 3 && tiles_r * c <= CU) { S = c; break; }
+    // worth it when the last round shrinks from one tile time to 1/S of one (+ ~1/4 for the slab round trip and the two extra
+    // launches) and that is >= 4 % of the kernel: 1029 tiles (4 rounds + 5: S = 8) and 344 tiles (1 round + 88: S = 2) both qualify
+    if (S >= 2 && (1.0 - 1.0 / S - 0.25) < 0.04 * (rounds + 1)) S = 0;
   }
   if (S < 2) return -1;
   const size_t slab = (size_t)R * N;
