@@ -29,6 +29,10 @@ tell which of two fp32 implementations is closer to the exact result).
 HIP fast path does (DESIGN.md "precision modes"); accumulation stays fp32.
 `emulate_bf16="fp8"` additionally fake-quantises the operands of the linears the fp8 mode
 runs on e4m3 MFMA (per-token / per-output-feature scales, torch.float8_e4m3fn rounding).
+`emulate_bf16="fp16x2"` evaluates the four linears of every backbone block with the H2 operand scheme of the fp16x2 mode
+(dinov2_od_amd/csrc/dod_common.h: x = h + l, h = fp16(x); x.w ~ h_x h_w + e4m3(h_x) e4m3(l_w 2^(e+11)) 2^-(e+11)
++ e4m3(l_x 2^11) e4m3(h_w 2^e) 2^-(e+11), e the weight row's power-of-two scale) and everything else exactly: the scheme's own
+distance from the reference, measurable without a GPU.
 """
 import math
 import torch
@@ -70,7 +74,28 @@ def _q8(t):
     return (t * (1.0 / sc)).to(torch.float8_e4m3fn).to(t.dtype) * sc
 
 
+def _e4m3(t):
+    return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(t.dtype)
+
+
+def _h2_product(x, w):
+    """x [.., K] . w [N, K]^T with the H2 operand scheme (packers: split_h2_kernel / h2_quad; product: gemm_h2_256x256_kernel)"""
+    x32, w32 = x.float().clamp(-65504.0, 65504.0), w.float().clamp(-65504.0, 65504.0)
+    hx, hw = x32.half().float(), w32.half().float()
+    lx, lw = x32 - hx, w32 - hw
+    amax = hw.abs().amax(dim=-1, keepdim=True)
+    e = torch.where(amax > 0, torch.floor(torch.log2(448.0 / amax.double())).float(), torch.zeros_like(amax))
+    sw = torch.exp2(e)
+    main = hx.double() @ hw.double().t()
+    cross = _e4m3(hx).double() @ (_e4m3(lw * sw * 2048.0) / (sw * 2048.0)).double().t() \
+        + (_e4m3(lx * 2048.0) / 2048.0).double() @ (_e4m3(hw * sw) / sw).double().t()
+    return (main + cross).to(x.dtype)
+
+
 def _linear(x, w, b, emu, fp8=False):
+    if emu == "fp16x2":
+        y = _h2_product(x, w)
+        return y if b is None else y + b
     if emu and fp8:
         x, w = _q8(x), _q8(w)          # per-token activation scales, per-output-feature weight scales
     elif emu:
@@ -87,7 +112,7 @@ def _maybe_lora_linear(sd, prefix, x, alpha, emu, fp8=False):
         w, b = sd(prefix + ".linear.weight"), sd(prefix + ".linear.bias")
         A, Bm = sd(prefix + ".lora_A.weight"), sd(prefix + ".lora_B.weight")
         if emu:
-            return _linear(x, w + alpha * (Bm @ A), b, True, fp8)
+            return _linear(x, w + alpha * (Bm @ A), b, emu, fp8)
         return x @ w.t() + b + alpha * ((x @ A.t()) @ Bm.t())
     return _linear(x, sd(prefix + ".weight"), sd(prefix + ".bias"), emu, fp8)
 
@@ -157,7 +182,8 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
                      emulate_bf16=False, prefix="backbone.", taps=None):
     """-> features [B, N, out_dim] (CLS token included: dinov2_backbone.py:60-61)."""
     sd = _SD(sd_raw, dtype)
-    emu = emulate_bf16
+    emu_lin = emulate_bf16                                   # the four linears of every block
+    emu = False if emulate_bf16 == "fp16x2" else emulate_bf16   # fp16x2: patch embed, attention, projection are split products (exact here)
     x = _t(pixel_values, dtype)
     B, Cc, H, W = x.shape
     if Cc != 3:
@@ -185,9 +211,9 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
         # K3-K6   modeling_dinov2.py:361-370
         y = _layernorm(h, sd(lp + "norm1.weight"), sd(lp + "norm1.bias"), bb.ln_eps)
         f8 = emu == "fp8"   # fp8 mode: QKV / out-proj / MLP-in (/ SwiGLU MLP-out) linears on e4m3 operands, the rest as the bf16 mode
-        q = _maybe_lora_linear(sd, lp + "attention.attention.query", y, a, emu, f8)
-        k = _maybe_lora_linear(sd, lp + "attention.attention.key", y, a, emu, f8)
-        v = _maybe_lora_linear(sd, lp + "attention.attention.value", y, a, emu, f8)
+        q = _maybe_lora_linear(sd, lp + "attention.attention.query", y, a, emu_lin, f8)
+        k = _maybe_lora_linear(sd, lp + "attention.attention.key", y, a, emu_lin, f8)
+        v = _maybe_lora_linear(sd, lp + "attention.attention.value", y, a, emu_lin, f8)
         if emu:
             q, k, v = _bf(q), _bf(k), _bf(v)
         q = q.view(B, N, nh, dh).transpose(1, 2)
@@ -205,23 +231,23 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
         ctx = ctx.transpose(1, 2).reshape(B, N, D)
         if emu == "fp8":
             ctx = _bf(ctx)            # the fp8 path stores the context in bf16, then quantises its rows
-        o = _maybe_lora_linear(sd, lp + "attention.output.dense", ctx, a, emu, emu == "fp8")
+        o = _maybe_lora_linear(sd, lp + "attention.output.dense", ctx, a, emu_lin, emu == "fp8")
         h = o * sd(lp + "layer_scale1.lambda1") + h
         if taps is not None and i == 0:
             taps["block0_attn"] = h.clone()
         # K7 / K7g   modeling_dinov2.py:373-380
         y = _layernorm(h, sd(lp + "norm2.weight"), sd(lp + "norm2.bias"), bb.ln_eps)
         if bb.swiglu:
-            z = _maybe_lora_linear(sd, lp + "mlp.weights_in", y, a, emu, f8)
+            z = _maybe_lora_linear(sd, lp + "mlp.weights_in", y, a, emu_lin, f8)
             if f8:
                 z = _bf(z)              # the fp8 path stores the MLP-in output in bf16 before the SwiGLU kernel
             x1, x2 = z.chunk(2, dim=-1)
             z = F.silu(x1) * x2
-            z = _maybe_lora_linear(sd, lp + "mlp.weights_out", z, a, emu, f8)
+            z = _maybe_lora_linear(sd, lp + "mlp.weights_out", z, a, emu_lin, f8)
         else:
-            z = _maybe_lora_linear(sd, lp + "mlp.fc1", y, a, emu, f8)
+            z = _maybe_lora_linear(sd, lp + "mlp.fc1", y, a, emu_lin, f8)
             z = 0.5 * z * (1.0 + torch.erf(z / math.sqrt(2.0)))   # exact-erf GELU
-            z = _maybe_lora_linear(sd, lp + "mlp.fc2", z, a, emu)
+            z = _maybe_lora_linear(sd, lp + "mlp.fc2", z, a, emu_lin)
         h = z * sd(lp + "layer_scale2.lambda1") + h
         if taps is not None:
             taps[f"block{i}"] = h.clone()
@@ -353,7 +379,8 @@ def detector_forward(sd, bb: BackboneConfig, dc: DecoderConfig, pixel_values,
     """DINOv2ObjectDetector.forward (detector.py:58-69) -> dict like the reference's."""
     with torch.no_grad():
         feats = backbone_forward(sd, bb, pixel_values, dtype, emulate_bf16, "backbone.", taps)
-        if emulate_bf16:
+        dec_emu = False if emulate_bf16 == "fp16x2" else emulate_bf16     # fp16x2: the decoder runs as in the fp32 mode
+        if dec_emu:
             feats = _bf(feats)      # HIP fast path hands bf16 memory to the decoder
-        logits, boxes = decoder_forward(sd, dc, feats, dtype, emulate_bf16, "decoder.", taps)
+        logits, boxes = decoder_forward(sd, dc, feats, dtype, dec_emu, "decoder.", taps)
     return {"pred_logits": logits, "pred_boxes": boxes, "features": feats}

@@ -68,6 +68,22 @@ def test_vitb_end_to_end(name, R, deform):
     assert rel_err(out["pred_boxes"].numpy(), g["pred_boxes"]) < 1e-3
 
 
+@pytest.mark.parametrize("name,R", [("g2_cfg1_q25", 224), ("g3_vitb_224", 224)])
+def test_fp16x2_operand_scheme_is_inside_the_gate(name, R):
+    """The fp16x2 mode's operand scheme (fp16 main product + e4m3 cross terms for the block linears), evaluated on the CPU: its own
+    distance from the REFERENCE's outputs sits inside the 1e-3 gate, and within a small factor of the fp32 oracle's (the GPU
+    tests hold the HIP path to the same goldens; this one separates the scheme from the kernels)."""
+    g = cases.golden(name)
+    bb, dc = cases.cfg1(25) if name.startswith("g2") else cases.vitb(100, True)
+    sd = synth.detector_state_dict(bb, dc, seed=1)
+    x = synth.make_pixels(2 if name.startswith("g2") else 1, R, R, seed=0)
+    out = orc.detector_forward(sd, bb, dc, x, emulate_bf16="fp16x2")
+    for k in ("pred_logits", "pred_boxes"):
+        e = cases.rel_err(out[k].numpy(), g[k])
+        print(f"{name} fp16x2 scheme {k}: {e:.2e}")
+        assert e < 1e-3, (k, e)
+
+
 @pytest.mark.parametrize("variant", ["large", "giant"])
 def test_oracle_full_depth_vs_reference(variant):
     """G7 / G8: BASELINE configs[3] / [4] at their workload (518x518, 300 queries, all 24 / 40 blocks, one image): the
