@@ -287,6 +287,10 @@ def roofline_leg(model, x, precision, steps, traffic=None, traffic_src=None):
     import torch
     eng = model._get_engine()
     nprof = max(3, min(10, steps))
+    # kernel durations are taken with the batch on ONE stream: the timed steps run it as concurrent micro-batches (engine.py
+    # micro_streams), under which two kernels share the chip and an event pair around one of them measures both
+    ms_saved = eng.micro_streams
+    eng.micro_streams = 1
     with torch.no_grad():
         eng.profile(True)
         for _ in range(nprof):
@@ -294,12 +298,14 @@ def roofline_leg(model, x, precision, steps, traffic=None, traffic_src=None):
         torch.cuda.synchronize()
         prof = eng.profile_read()
         eng.profile(False)
+    eng.micro_streams = ms_saved
     d = prof[DOMINANT[precision]]
     peak = PEAK[precision]
     ach = d["flops"] / (d["ms"] * 1e-3) if d["ms"] > 0 else 0.0
     return {"bound": "mfma", "kernel": KERNEL_NAMES[precision],
             "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+            "measured": "HIP event pairs per launch over extra forwards right after the timed region, the batch on one stream (DINODET_MICRO_STREAMS=1: the timed steps overlap two micro-batches, under which per-kernel durations are not separable)",
             "launches_per_step": d["launches"] // nprof, "avg_launch_us": 1e3 * d["ms"] / max(1, d["launches"]),
             "flops_per_launch_avg": d["flops"] / max(1, d["launches"]),
             "class_ms_per_step": d["ms"] / nprof,
@@ -399,7 +405,8 @@ def worker(a):
                       "parallelism": f"dp{world}", "hipgraph": st.graph is not None, "n_ranks_seen": n_ranks_seen,
                       "collective": None if world == 1 else ("all_gather_into_tensor of packed [B_local,Q,C+4] fp32 per step, "
                                                              + ("side stream, overlapped with the next forward" if st.overlap else "compute stream")),
-                      "gather_checked": gather_ok},
+                      "gather_checked": gather_ok,
+                      "micro_batches": None if cpu else (lambda e: e.micro_streams if (B_local >= e.micro_min_batch and B_local % e.micro_streams == 0) else 1)(model._get_engine())},
            "step_ms_p10_p50_p90": pcts}
     if cpu:
         res["metric"] = "REHEARSAL (CPU stub model, gloo): control flow only, not a measurement"

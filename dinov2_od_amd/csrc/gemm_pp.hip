@@ -862,17 +862,31 @@ __global__ __launch_bounds__(512) void gemm_ksplit_reduce_kernel(const float* __
   else drain_tile<KSR_ROWS, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m_base + r0 + row_l; });
 }
 
+// scratch: TAIL_SLOTS slabs per device, one per launching stream (a forward may run as concurrent micro-batches on separate streams:
+// engine.py); a stream that finds no free slab takes the unsplit path
+#define TAIL_SLOTS 2
 static float* g_tail_scratch[16] = {};
-static size_t g_tail_bytes[16] = {};
+static size_t g_tail_bytes[16] = {};           // bytes per slab
+static hipStream_t g_tail_owner[16][TAIL_SLOTS] = {};
+static bool g_tail_owned[16][TAIL_SLOTS] = {};
 int gemm_tail_reserve(size_t bytes) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 3;
   if (g_tail_bytes[dev] >= bytes) return 0;
   if (g_tail_scratch[dev]) (void)hipFree(g_tail_scratch[dev]);
   g_tail_scratch[dev] = nullptr; g_tail_bytes[dev] = 0;
-  if (hipMalloc((void**)&g_tail_scratch[dev], bytes) != hipSuccess) return 3;
+  for (int i = 0; i < TAIL_SLOTS; ++i) g_tail_owned[dev][i] = false;
+  if (hipMalloc((void**)&g_tail_scratch[dev], bytes * TAIL_SLOTS) != hipSuccess) return 3;
   g_tail_bytes[dev] = bytes;
   return 0;
+}
+static float* tail_slab(int dev, hipStream_t s) {
+  if (!g_tail_scratch[dev]) return nullptr;
+  for (int i = 0; i < TAIL_SLOTS; ++i)
+    if (g_tail_owned[dev][i] && g_tail_owner[dev][i] == s) return (float*)((char*)g_tail_scratch[dev] + (size_t)i * g_tail_bytes[dev]);
+  for (int i = 0; i < TAIL_SLOTS; ++i)
+    if (!g_tail_owned[dev][i]) { g_tail_owned[dev][i] = true; g_tail_owner[dev][i] = s; return (float*)((char*)g_tail_scratch[dev] + (size_t)i * g_tail_bytes[dev]); }
+  return nullptr;
 }
 
 static thread_local bool t_in_tail_split = false;
@@ -920,8 +934,9 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   }
   if (S < 2) return -1;
   const size_t slab = (size_t)R * N;
-  if (g_tail_bytes[dev] < slab * S * 4 || !g_tail_scratch[dev]) return -1;           // reserved outside stream capture (gemm_tail_reserve)
-  float* scratch = g_tail_scratch[dev];
+  if (g_tail_bytes[dev] < slab * S * 4) return -1;           // reserved outside stream capture (gemm_tail_reserve)
+  float* scratch = tail_slab(dev, s);
+  if (!scratch) return -1;
   // ---- main rows: the caller's own dispatch
   if (Mmain > 0) {
     t_in_tail_split = true;

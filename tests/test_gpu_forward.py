@@ -305,6 +305,31 @@ def test_hipgraph_replay_matches_eager_and_tracks_weight_updates(G):
     assert torch.equal(m.forward_packed(xa), g2) and not torch.equal(g2, ea)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "fp16x2"])
+def test_concurrent_micro_batches_are_bit_identical(G, precision):
+    """engine.micro_streams: a large batch runs as concurrent micro-batches on separate HIP streams (fork / join), eagerly, inside the
+    engine's own captured graph and inside a caller's capture (bench.py).  Images are independent: the detections must equal the
+    single-launch forward's bit for bit."""
+    bb, dc = cases.cfg1(25)
+    m = G.make_detector(bb, dc, precision, "facebook/dinov2-small")
+    x = G.to_gpu(synth.make_pixels(4, 224, 224, seed=0))
+    eng = m._get_engine()
+    eng.micro_streams = 1
+    single = m.forward_packed(x).clone()
+    eng.micro_streams, eng.micro_min_batch = 2, 2
+    assert torch.equal(m.forward_packed(x), single)                      # eager fork / join
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):         # a caller's capture: the side streams join it
+        out = m.forward_packed(x)
+    g.replay()
+    G.sync()
+    assert torch.equal(out, single)
+    m.enable_hipgraph()
+    for _ in range(2):                                                   # the engine's own graph: capture, then replay
+        assert torch.equal(m.forward_packed(x), single)
+    m.enable_hipgraph(False)
+
+
 def test_hipgraph_small_shape_survives_a_later_larger_one(G):
     """a captured graph bakes in the address of its workspace: a later, larger shape (or an eager call that needs more scratch)
     must not pull it from under the earlier graph.  Capture small, then large, run eager calls of other shapes, replay small."""
