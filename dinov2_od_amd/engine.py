@@ -53,7 +53,8 @@ class Engine:
         # Graph replays of a large batch run it as `micro_streams` concurrent micro-batches on separate HIP streams (fork / join
         # inside the captured graph, one workspace each, one shared output buffer): images are independent, and one micro-batch's
         # LayerNorm / epilogue / last-round bubbles are filled by the other's GEMMs -- measured +4-5 % at batch 64 x 518^2 with
-        # bit-identical detections (tools/bench_two_streams.py).  DINODET_MICRO_STREAMS=1 switches it off.
+        # bit-identical detections (tools/bench_two_streams.py); four micro-batches lose (1 993 vs 2 167 images/s) and a start skew
+        # between the streams (13 us .. 1.2 ms) changes nothing.  DINODET_MICRO_STREAMS=1 switches it off.
         self.micro_streams = max(1, int(os.environ.get("DINODET_MICRO_STREAMS", "2")))
         self.micro_min_batch = int(os.environ.get("DINODET_MICRO_MIN_BATCH", "32"))
         self._micro = {}    # (micro-batch, H, W, device) -> (workspaces, side streams) of the eager / caller-captured path
