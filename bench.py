@@ -406,7 +406,7 @@ def worker(a):
                       "collective": None if world == 1 else ("all_gather_into_tensor of packed [B_local,Q,C+4] fp32 per step, "
                                                              + ("side stream, overlapped with the next forward" if st.overlap else "compute stream")),
                       "gather_checked": gather_ok,
-                      "micro_batches": None if cpu else (lambda e: e.micro_streams if (B_local >= e.micro_min_batch and B_local % e.micro_streams == 0) else 1)(model._get_engine())},
+                      "micro_batches": None if cpu else (lambda e: e.micro_streams if e._micro_ok(B_local, R, R) else 1)(model._get_engine())},
            "step_ms_p10_p50_p90": pcts}
     if cpu:
         res["metric"] = "REHEARSAL (CPU stub model, gloo): control flow only, not a measurement"

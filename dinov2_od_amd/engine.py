@@ -56,7 +56,10 @@ class Engine:
         # bit-identical detections (tools/bench_two_streams.py); four micro-batches lose (1 993 vs 2 167 images/s) and a start skew
         # between the streams (13 us .. 1.2 ms) changes nothing.  DINODET_MICRO_STREAMS=1 switches it off.
         self.micro_streams = max(1, int(os.environ.get("DINODET_MICRO_STREAMS", "2")))
-        self.micro_min_batch = int(os.environ.get("DINODET_MICRO_MIN_BATCH", "32"))
+        # threshold in TOKEN ROWS of the batch (images x tokens), not images: 16 images of 518^2 (ViT-L: 21 920 rows) gain 7 %, 32
+        # images of 224^2 (8 224 rows) nothing, 32 images of 518^2 on ViT-g nothing (measured)
+        self.micro_min_rows = int(os.environ.get("DINODET_MICRO_MIN_ROWS", "16384"))
+        self.micro_min_batch = int(os.environ.get("DINODET_MICRO_MIN_BATCH", "2"))
         self._micro = {}    # (micro-batch, H, W, device) -> (workspaces, side streams) of the eager / caller-captured path
 
     def close(self):
@@ -140,7 +143,7 @@ class Engine:
         if ent is None:
             xs = x.clone()
             B, _, H, W = x.shape
-            K = self.micro_streams if (B >= self.micro_min_batch and B % self.micro_streams == 0) else 1
+            K = self.micro_streams if self._micro_ok(B, H, W) else 1
             Bk = B // K
             parts = [(xs[k * Bk:(k + 1) * Bk], torch.empty(self._lib.dod_workspace_bytes(self._h, Bk, H, W), dtype=torch.uint8, device=x.device))
                      for k in range(K)]
@@ -180,12 +183,17 @@ class Engine:
                                         nat.stream_ptr()), self._h)
         return det
 
+    def _micro_ok(self, B, H, W):
+        K = self.micro_streams
+        return (K >= 2 and B >= self.micro_min_batch and B % K == 0
+                and B * self._lib.dod_num_tokens(self._h, H, W) >= self.micro_min_rows)
+
     def _launch_micro(self, x):
         """the forward of a large batch as `micro_streams` concurrent micro-batches (fork / join on side streams; inside a caller's
         stream capture the side streams join the capture).  Detections are bit-identical to the single launch."""
         B, _, H, W = x.shape
         K = self.micro_streams
-        if K < 2 or B < self.micro_min_batch or B % K or self._tap_bufs:
+        if not self._micro_ok(B, H, W) or self._tap_bufs:
             return self._launch_forward(x)
         Bk = B // K
         key = (Bk, H, W, x.device)

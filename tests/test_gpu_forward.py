@@ -316,7 +316,7 @@ def test_concurrent_micro_batches_are_bit_identical(G, precision):
     eng = m._get_engine()
     eng.micro_streams = 1
     single = m.forward_packed(x).clone()
-    eng.micro_streams, eng.micro_min_batch = 2, 2
+    eng.micro_streams, eng.micro_min_batch, eng.micro_min_rows = 2, 2, 0
     assert torch.equal(m.forward_packed(x), single)                      # eager fork / join
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, capture_error_mode="thread_local"):         # a caller's capture: the side streams join it
