@@ -190,8 +190,8 @@ int launch_gemm_fp8_pp(const unsigned char* A, int lda, const unsigned char* W, 
 // (every tile of the remainder as S slices on S CUs, fp32 partials to a scratch buffer) plus a reduce + epilogue launch.
 // kind: 0 plain bf16 (ppm kernel), 1 split product, 2 H2.  Returns 0 when done, -1 when the shape does not qualify (caller
 // launches normally), > 0 on error.  gemm_tail_reserve(bytes): allocate the scratch outside any stream capture.  The scratch is one
-// slab per launching stream (two per device: a forward may run as two concurrent micro-batches on two streams, engine.py); a third
-// stream takes the unsplit path.  The slices are summed in a fixed order, so results do not depend on scheduling.
+// slab per launching stream (four per device, least-recently-used first: a forward may run as two concurrent micro-batches on two
+// streams, engine.py).  The slices are summed in a fixed order, so results do not depend on scheduling.
 int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 int gemm_tail_reserve(size_t bytes);
 // split-product GEMM on pair-layout operands A2 [M, 2K], W2 [N, 2K] (gemm_x3.hip)

@@ -862,31 +862,39 @@ __global__ __launch_bounds__(512) void gemm_ksplit_reduce_kernel(const float* __
   else drain_tile<KSR_ROWS, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m_base + r0 + row_l; });
 }
 
-// scratch: TAIL_SLOTS slabs per device, one per launching stream (a forward may run as concurrent micro-batches on separate streams:
-// engine.py); a stream that finds no free slab takes the unsplit path
-#define TAIL_SLOTS 2
+// scratch: TAIL_SLOTS slabs per device, handed to launching streams least-recently-used first (a forward may run as concurrent
+// micro-batches on separate streams -- engine.py: two -- and a process creates many short-lived streams over time: warm-up, capture,
+// side streams).  Streams that launch concurrently must not share a slab: up to TAIL_SLOTS of them never do.
+#define TAIL_SLOTS 4
 static float* g_tail_scratch[16] = {};
 static size_t g_tail_bytes[16] = {};           // bytes per slab
 static hipStream_t g_tail_owner[16][TAIL_SLOTS] = {};
-static bool g_tail_owned[16][TAIL_SLOTS] = {};
+static unsigned long long g_tail_used[16][TAIL_SLOTS] = {};
+static unsigned long long g_tail_clock = 0;
 int gemm_tail_reserve(size_t bytes) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 3;
   if (g_tail_bytes[dev] >= bytes) return 0;
   if (g_tail_scratch[dev]) (void)hipFree(g_tail_scratch[dev]);
   g_tail_scratch[dev] = nullptr; g_tail_bytes[dev] = 0;
-  for (int i = 0; i < TAIL_SLOTS; ++i) g_tail_owned[dev][i] = false;
+  for (int i = 0; i < TAIL_SLOTS; ++i) { g_tail_used[dev][i] = 0; g_tail_owner[dev][i] = nullptr; }
   if (hipMalloc((void**)&g_tail_scratch[dev], bytes * TAIL_SLOTS) != hipSuccess) return 3;
   g_tail_bytes[dev] = bytes;
   return 0;
 }
 static float* tail_slab(int dev, hipStream_t s) {
   if (!g_tail_scratch[dev]) return nullptr;
+  int pick = -1;
   for (int i = 0; i < TAIL_SLOTS; ++i)
-    if (g_tail_owned[dev][i] && g_tail_owner[dev][i] == s) return (float*)((char*)g_tail_scratch[dev] + (size_t)i * g_tail_bytes[dev]);
-  for (int i = 0; i < TAIL_SLOTS; ++i)
-    if (!g_tail_owned[dev][i]) { g_tail_owned[dev][i] = true; g_tail_owner[dev][i] = s; return (float*)((char*)g_tail_scratch[dev] + (size_t)i * g_tail_bytes[dev]); }
-  return nullptr;
+    if (g_tail_used[dev][i] && g_tail_owner[dev][i] == s) { pick = i; break; }
+  if (pick < 0) {
+    pick = 0;
+    for (int i = 1; i < TAIL_SLOTS; ++i)
+      if (g_tail_used[dev][i] < g_tail_used[dev][pick]) pick = i;
+    g_tail_owner[dev][pick] = s;
+  }
+  g_tail_used[dev][pick] = ++g_tail_clock;
+  return (float*)((char*)g_tail_scratch[dev] + (size_t)pick * g_tail_bytes[dev]);
 }
 
 static thread_local bool t_in_tail_split = false;
