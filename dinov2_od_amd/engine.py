@@ -56,9 +56,10 @@ class Engine:
         # bit-identical detections (tools/bench_two_streams.py); four micro-batches lose (1 993 vs 2 167 images/s) and a start skew
         # between the streams (13 us .. 1.2 ms) changes nothing.  DINODET_MICRO_STREAMS=1 switches it off.
         self.micro_streams = max(1, int(os.environ.get("DINODET_MICRO_STREAMS", "2")))
-        # threshold in TOKEN ROWS of the batch (images x tokens), not images: 16 images of 518^2 (ViT-L: 21 920 rows) gain 7 %, 32
-        # images of 224^2 (8 224 rows) nothing, 32 images of 518^2 on ViT-g nothing (measured)
-        self.micro_min_rows = int(os.environ.get("DINODET_MICRO_MIN_ROWS", "16384"))
+        # threshold in TOKEN ROWS of the batch (images x tokens), not images: 16 images of 518^2 (ViT-L: 21 920 rows) gain 7 %, 8
+        # images of 518^2 (10 960 rows: BASELINE configs[2] sharded over 8 GPUs) 10 %, 32 images of 224^2 (8 224 rows) nothing, 32
+        # images of 518^2 on ViT-g nothing (measured)
+        self.micro_min_rows = int(os.environ.get("DINODET_MICRO_MIN_ROWS", "10000"))
         self.micro_min_batch = int(os.environ.get("DINODET_MICRO_MIN_BATCH", "2"))
         self._micro = {}    # (micro-batch, H, W, device) -> (workspaces, side streams) of the eager / caller-captured path
 
