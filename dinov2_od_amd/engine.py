@@ -144,7 +144,7 @@ class Engine:
         if ent is None:
             xs = x.clone()
             B, _, H, W = x.shape
-            K = self.micro_streams if self._micro_ok(B, H, W) else 1
+            K = self.micro_streams if (self._micro_ok(B, H, W) and B % self.micro_streams == 0) else 1
             Bk = B // K
             parts = [(xs[k * Bk:(k + 1) * Bk], torch.empty(self._lib.dod_workspace_bytes(self._h, Bk, H, W), dtype=torch.uint8, device=x.device))
                      for k in range(K)]
@@ -186,7 +186,7 @@ class Engine:
 
     def _micro_ok(self, B, H, W):
         K = self.micro_streams
-        return (K >= 2 and B >= self.micro_min_batch and B % K == 0
+        return (K >= 2 and B >= max(self.micro_min_batch, K)
                 and B * self._lib.dod_num_tokens(self._h, H, W) >= self.micro_min_rows)
 
     def _launch_micro(self, x):
@@ -196,25 +196,28 @@ class Engine:
         K = self.micro_streams
         if not self._micro_ok(B, H, W) or self._tap_bufs:
             return self._launch_forward(x)
-        Bk = B // K
-        key = (Bk, H, W, x.device)
+        sizes = [B // K + (1 if k < B % K else 0) for k in range(K)]
+        offs = [sum(sizes[:k]) for k in range(K)]
+        key = (tuple(sizes), H, W, x.device)
         st = self._micro.get(key)
         if st is None:
-            nb = self._lib.dod_workspace_bytes(self._h, Bk, H, W)
-            if nb == 0:
-                raise ValueError(f"unsupported input {tuple(x.shape)}")
-            st = ([torch.empty(nb, dtype=torch.uint8, device=x.device) for _ in range(K)],
-                  [torch.cuda.Stream(device=x.device) for _ in range(K - 1)])
+            wss = []
+            for bk in sizes:
+                nb = self._lib.dod_workspace_bytes(self._h, bk, H, W)
+                if nb == 0:
+                    raise ValueError(f"unsupported input {tuple(x.shape)}")
+                wss.append(torch.empty(nb, dtype=torch.uint8, device=x.device))
+            st = (wss, [torch.cuda.Stream(device=x.device) for _ in range(K - 1)])
             self._micro[key] = st
         wss, side = st
         det = torch.empty(B, self.dc.num_queries, self.dc.num_classes + 4, dtype=torch.float32, device=x.device)
         cur = torch.cuda.current_stream(x.device)
         for sd in side:
             sd.wait_stream(cur)                              # fork: x (and det's allocation) are ready on `cur`
-        self._launch_forward(x[:Bk], wss[0], det[:Bk])
+        self._launch_forward(x[:sizes[0]], wss[0], det[:sizes[0]])
         for k, sd in enumerate(side, start=1):
             with torch.cuda.stream(sd):
-                self._launch_forward(x[k * Bk:(k + 1) * Bk], wss[k], det[k * Bk:(k + 1) * Bk])
+                self._launch_forward(x[offs[k]:offs[k] + sizes[k]], wss[k], det[offs[k]:offs[k] + sizes[k]])
         for sd in side:
             cur.wait_stream(sd)                              # join
         return det
