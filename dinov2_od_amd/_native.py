@@ -79,6 +79,8 @@ SYMBOLS = {
     "dod_profile": (_I, [_P, _I]),
     "dod_profile_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dod_op_linear": (_I, [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "dod_op_gemm_f32x": (_I, [_P, _I, _I, C.c_longlong, C.c_longlong, _P, _I, _I, C.c_longlong, C.c_longlong, _P, _I, C.c_longlong, C.c_longlong,
+                         _I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "dod_op_linear_fp8": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "dod_op_quant_rows_fp8": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "dod_op_split_pair": (_I, [_P, _I, _I, _I, _P, _P]),

@@ -9,9 +9,11 @@
 //   backward : the exact adjoint of each step; weight gradients ACCUMULATE (the layers share one set of weights, and the
 //              caller may accumulate over micro-batches); d(values) is a float-atomic scatter-add of the same four corners the
 //              forward gathered (floor / clamp carry no gradient; torch.clamp passes it inside [0, 1] inclusive).
-// Linear backward runs on the fp32 MFMA GEMM of the forward (gemm_f32.hip: C = A W^T): dX = dY (W^T)^T and dW = dY^T (X^T)^T on
-// transposed, zero-padded copies.  Dropout masks come from a counter-based hash of (seed, site, element): the backward
-// regenerates them, nothing but activations is taped.
+// Linear backward runs on the fp32 MFMA GEMM of the forward in its k-major-operand form (gemm_f32.hip, launch_gemm_f32x): dX = dY W
+// reads W as the k-major operand, dW += dY^T X reads both operands k-major with the row dimension split over the grid (atomic
+// accumulate) -- no transposed copies.  Self-attention (forward and adjoint) is batched GEMMs over (image, head) around one row
+// kernel.  Dropout masks come from a counter-based hash of (seed, site, element): the backward regenerates them, nothing but
+// activations is taped.
 #include "dod_common.h"
 #include "../../include/dinodet.h"
 
@@ -38,27 +40,6 @@ __host__ __device__ inline unsigned long long site_key(unsigned long long seed, 
 }
 
 // ------------------------------------------------------------------------------------------------ small kernels
-// dst[c][r] = src[r][c]; dst has ld_dst >= rows columns, columns rows..ld_dst-1 are zeroed
-__global__ void transpose_pad_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, float* __restrict__ dst, int ld_dst) {
-  __shared__ float t[32][33];
-  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: 8 rows per pass
-  for (int i = ty; i < 32; i += 8) {
-    const int r = r0 + i, c = c0 + tx;
-    t[i][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : 0.f;
-  }
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
-    const int c = c0 + i, r = r0 + tx;
-    if (c < cols && r < ld_dst) dst[(size_t)c * ld_dst + r] = t[tx][i];
-  }
-}
-int transpose_pad(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t s) {
-  dim3 g((ld_dst + 31) / 32, (cols + 31) / 32);
-  hipLaunchKernelGGL(transpose_pad_kernel, g, dim3(256), 0, s, src, ld_src, rows, cols, dst, ld_dst);
-  return hipGetLastError() == hipSuccess ? 0 : 3;
-}
-
 // dst[c] += sum_r src[r][c]
 __global__ void colsum_kernel(const float* __restrict__ src, int ld, int rows, int cols, float* __restrict__ dst) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -134,10 +115,6 @@ __global__ void gelu_fwd_kernel(const float* __restrict__ pre, float* __restrict
 __global__ void colscale_kernel(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ out, size_t n, int D) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] * v[i % D];
 }
-__global__ void fill_kernel(float* __restrict__ a, float v, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) a[i] = v;
-}
 // dq[q][:] += sum_b d[b][q][:]
 __global__ void batch_sum_kernel(const float* __restrict__ d, float* __restrict__ dq, int B, size_t per) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
@@ -202,158 +179,122 @@ int ln_bwd(const float* x, const float* gamma, const float* dy, float eps, int r
 
 // ------------------------------------------------------------------------------------------------ multi-head self-attention (Q x Q)
 // nn.MultiheadAttention (deformable_attention.py:195, 233): softmax((q k^T) / sqrt(dh)), dropout on the probabilities, times v.
-// qkv [B*Q, 3*Dd] = [q | k | v], head h at columns h*dh.  One wave per (b, head, query row).
+// qkv [B*Q, 3*Dd] = [q | k | v], head h at columns h*dh.  Scores, probabilities and their adjoints are [B*Hd, Q, Qp] fp32 scratch
+// (Qp = Q rounded up to 4); every product is one batched fp32-MFMA GEMM over (image, head) on strided views of qkv / dO / dqkv:
+//   forward : S = scale q k^T  ->  row kernel: Pd = dropout(softmax(S))  ->  O = Pd v
+//   backward: S = scale q k^T, dP = dO v^T  ->  row kernel: Pd, dS = P (keep dP - sum_j keep dP P)
+//             ->  dq = scale dS k,  dk = scale dS^T q,  dv = Pd^T dO
+// (Round 2 first ran one wave per query row on the VALU -- 2.2 ms per ViT-B block backward at 16 x 257 tokens, every wave
+// re-reading K and V from L2 -- and an LDS-resident workgroup per (image, head), which was 2x slower still: 192 workgroups of four
+// waves left each SIMD one latency-bound wave.)
 #define MHA_MAXQ 1408      // decoder queries, and the 1370 tokens of a 518x518 image in the backbone-tail backward
-__device__ __forceinline__ void mha_row_probs(const float* __restrict__ qkv, int ld, int b, int h, int i, int Q, int Dd, int dh, float scale,
-                                              float* __restrict__ sp, int lane) {
-  const float* qi = qkv + ((size_t)b * Q + i) * ld + h * dh;
+#define MHA_RT (MHA_MAXQ / 64)
+
+// one wave per score row; item = (b*Hd + h)*Q + i is also the dropout counter base (mask element = item*Q + j)
+__global__ __launch_bounds__(256) void mha_softmax_fwd_kernel(float* __restrict__ S, int Q, int Qp, long nrows, float p, unsigned long long key) {
+  const int lane = threadIdx.x & 63;
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= nrows) return;
+  float* row = S + (size_t)item * Qp;
+  float v[MHA_RT];
   float mx = -INFINITY;
-  for (int j = lane; j < Q; j += 64) {
-    const float* kj = qkv + ((size_t)b * Q + j) * ld + Dd + h * dh;
-    float acc = 0.f;
-    for (int d = 0; d < dh; d += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(qi + d), k4 = *reinterpret_cast<const float4*>(kj + d);
-      acc += a.x * k4.x + a.y * k4.y + a.z * k4.z + a.w * k4.w;
-    }
-    acc *= scale;
-    sp[j] = acc;
-    mx = fmaxf(mx, acc);
-  }
+#pragma unroll
+  for (int t = 0; t < MHA_RT; ++t) { const int j = lane + 64 * t; v[t] = j < Q ? row[j] : -INFINITY; mx = fmaxf(mx, v[t]); }
   mx = wave_max(mx);
   float sum = 0.f;
-  for (int j = lane; j < Q; j += 64) { const float e = expf(sp[j] - mx); sp[j] = e; sum += e; }
+#pragma unroll
+  for (int t = 0; t < MHA_RT; ++t) { const int j = lane + 64 * t; v[t] = j < Q ? expf(v[t] - mx) : 0.f; sum += v[t]; }
   sum = wave_sum(sum);
-  const float inv = 1.0f / sum;
-  for (int j = lane; j < Q; j += 64) sp[j] *= inv;
-}
-
-__global__ __launch_bounds__(256) void mha_fwd_train_kernel(const float* __restrict__ qkv, int ld, float* __restrict__ out, int ldo, int B,
-                                                            int Q, int Hd, int Dd, int dh, float scale, float p, unsigned long long key) {
-  __shared__ float sP[4][MHA_MAXQ];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long item = (long)blockIdx.x * 4 + w;
-  if (item >= (long)B * Hd * Q) return;
-  const int i = (int)(item % Q);
-  const long bh = item / Q;
-  const int h = (int)(bh % Hd), b = (int)(bh / Hd);
-  float* sp = sP[w];
-  mha_row_probs(qkv, ld, b, h, i, Q, Dd, dh, scale, sp, lane);
-  if (p > 0.f) {
-    const float inv = 1.0f / (1.0f - p);
-    for (int j = lane; j < Q; j += 64) sp[j] = u01(key, (unsigned long long)item * Q + j) >= p ? sp[j] * inv : 0.f;
-  }
-  // O_i[d] = sum_j P_ij v_j[d]; lanes along d (two columns per lane when dh > 64)
-  const float* vb = qkv + (size_t)b * Q * ld + 2 * Dd + h * dh;
-  float o0 = 0.f, o1 = 0.f;
-  const bool d0 = lane < dh, d1 = lane + 64 < dh;
-  for (int j = 0; j < Q; ++j) {
-    const float pj = sp[j];
-    const float* vj = vb + (size_t)j * ld;
-    if (d0) o0 += pj * vj[lane];
-    if (d1) o1 += pj * vj[lane + 64];
-  }
-  float* op = out + ((size_t)b * Q + i) * ldo + h * dh;
-  if (d0) op[lane] = o0;
-  if (d1) op[lane + 64] = o1;
-}
-
-// row pass: dS[b,h,i,:], Pd[b,h,i,:] (dropped probabilities) to scratch, dq_i
-__global__ __launch_bounds__(256) void mha_bwd_row_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dO, int ldo,
-                                                          float* __restrict__ dqkv, float* __restrict__ dS, float* __restrict__ Pd, int B, int Q,
-                                                          int Hd, int Dd, int dh, float scale, float p, unsigned long long key) {
-  __shared__ float sP[4][MHA_MAXQ];
-  __shared__ float sD[4][MHA_MAXQ];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long item = (long)blockIdx.x * 4 + w;
-  if (item >= (long)B * Hd * Q) return;
-  const int i = (int)(item % Q);
-  const long bh = item / Q;
-  const int h = (int)(bh % Hd), b = (int)(bh / Hd);
-  float* sp = sP[w];
-  float* sd = sD[w];
-  mha_row_probs(qkv, ld, b, h, i, Q, Dd, dh, scale, sp, lane);
-  const float* doi = dO + ((size_t)b * Q + i) * ldo + h * dh;
-  const float inv = 1.0f / (1.0f - p);
-  float dot = 0.f;
-  for (int j = lane; j < Q; j += 64) {
-    const float* vj = qkv + ((size_t)b * Q + j) * ld + 2 * Dd + h * dh;
-    float acc = 0.f;
-    for (int d = 0; d < dh; d += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(doi + d), v4 = *reinterpret_cast<const float4*>(vj + d);
-      acc += a.x * v4.x + a.y * v4.y + a.z * v4.z + a.w * v4.w;
+  const float inv = 1.0f / sum, invk = 1.0f / (1.0f - p);
+#pragma unroll
+  for (int t = 0; t < MHA_RT; ++t) {
+    const int j = lane + 64 * t;
+    if (j < Qp) {
+      float o = v[t] * inv;
+      if (p > 0.f && j < Q) o = u01(key, (unsigned long long)item * Q + j) >= p ? o * invk : 0.f;
+      row[j] = j < Q ? o : 0.f;
     }
+  }
+}
+// SP: scores in, dropped probabilities out;  DD: d(loss)/d(dropped probabilities) in, d(loss)/d(scores) out
+__global__ __launch_bounds__(256) void mha_softmax_bwd_kernel(float* __restrict__ SP, float* __restrict__ DD, int Q, int Qp, long nrows, float p,
+                                                              unsigned long long key) {
+  const int lane = threadIdx.x & 63;
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= nrows) return;
+  float* srow = SP + (size_t)item * Qp;
+  float* drow = DD + (size_t)item * Qp;
+  float v[MHA_RT], g[MHA_RT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < MHA_RT; ++t) { const int j = lane + 64 * t; v[t] = j < Q ? srow[j] : -INFINITY; g[t] = j < Q ? drow[j] : 0.f; mx = fmaxf(mx, v[t]); }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < MHA_RT; ++t) { const int j = lane + 64 * t; v[t] = j < Q ? expf(v[t] - mx) : 0.f; sum += v[t]; }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum, invk = 1.0f / (1.0f - p);
+  float dot = 0.f;
+#pragma unroll
+  for (int t = 0; t < MHA_RT; ++t) {
+    const int j = lane + 64 * t;
+    v[t] *= inv;
     float keepf = 1.0f;
-    if (p > 0.f) keepf = u01(key, (unsigned long long)item * Q + j) >= p ? inv : 0.f;
-    const float dP = acc * keepf;          // d(loss) / d(P_ij) through the dropout
-    sd[j] = dP;
-    dot += dP * sp[j];
-    Pd[(size_t)item * Q + j] = sp[j] * keepf;
+    if (p > 0.f && j < Q) keepf = u01(key, (unsigned long long)item * Q + j) >= p ? invk : 0.f;
+    g[t] *= keepf;                         // d(loss) / d(P_ij) through the dropout
+    dot += g[t] * v[t];
+    if (j < Qp) srow[j] = j < Q ? v[t] * keepf : 0.f;
   }
   dot = wave_sum(dot);
-  for (int j = lane; j < Q; j += 64) {
-    const float ds = sp[j] * (sd[j] - dot);
-    sd[j] = ds;
-    dS[(size_t)item * Q + j] = ds;
+#pragma unroll
+  for (int t = 0; t < MHA_RT; ++t) {
+    const int j = lane + 64 * t;
+    if (j < Qp) drow[j] = j < Q ? v[t] * (g[t] - dot) : 0.f;
   }
-  // dq_i[d] = scale * sum_j dS_ij k_j[d]
-  const float* kb = qkv + (size_t)b * Q * ld + Dd + h * dh;
-  float q0 = 0.f, q1 = 0.f;
-  const bool d0 = lane < dh, d1 = lane + 64 < dh;
-  for (int j = 0; j < Q; ++j) {
-    const float ds = sd[j];
-    const float* kj = kb + (size_t)j * ld;
-    if (d0) q0 += ds * kj[lane];
-    if (d1) q1 += ds * kj[lane + 64];
-  }
-  float* dq = dqkv + ((size_t)b * Q + i) * ld + h * dh;
-  if (d0) dq[lane] = q0 * scale;
-  if (d1) dq[lane + 64] = q1 * scale;
-}
-// column pass: dk_j = scale * sum_i dS_ij q_i, dv_j = sum_i Pd_ij dO_i
-__global__ __launch_bounds__(256) void mha_bwd_col_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dO, int ldo,
-                                                          float* __restrict__ dqkv, const float* __restrict__ dS, const float* __restrict__ Pd,
-                                                          int B, int Q, int Hd, int Dd, int dh, float scale) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long item = (long)blockIdx.x * 4 + w;
-  if (item >= (long)B * Hd * Q) return;
-  const int j = (int)(item % Q);
-  const long bh = item / Q;
-  const int h = (int)(bh % Hd), b = (int)(bh / Hd);
-  const float* qb = qkv + (size_t)b * Q * ld + h * dh;
-  const float* dob = dO + (size_t)b * Q * ldo + h * dh;
-  const float* dsb = dS + (size_t)bh * Q * Q + j;
-  const float* pdb = Pd + (size_t)bh * Q * Q + j;
-  float k0 = 0.f, k1 = 0.f, v0 = 0.f, v1 = 0.f;
-  const bool d0 = lane < dh, d1 = lane + 64 < dh;
-  for (int i = 0; i < Q; ++i) {
-    const float ds = dsb[(size_t)i * Q], pd = pdb[(size_t)i * Q];
-    const float* qi = qb + (size_t)i * ld;
-    const float* di = dob + (size_t)i * ldo;
-    if (d0) { k0 += ds * qi[lane]; v0 += pd * di[lane]; }
-    if (d1) { k1 += ds * qi[lane + 64]; v1 += pd * di[lane + 64]; }
-  }
-  float* dk = dqkv + ((size_t)b * Q + j) * ld + Dd + h * dh;
-  float* dv = dqkv + ((size_t)b * Q + j) * ld + 2 * Dd + h * dh;
-  if (d0) { dk[lane] = k0 * scale; dv[lane] = v0; }
-  if (d1) { dk[lane + 64] = k1 * scale; dv[lane + 64] = v1; }
 }
 
-// (An LDS-resident variant -- one workgroup per (image, head), K / V then Q / dO staged as [N][dh + 1] fp32 -- was built and measured
-// on the ViT-B tail, 257 tokens x 12 heads x 16 images: 1 803 us for the backward against 589 + 258 us for the two kernels above, and
-// 373 against 175 us for the forward: 192 workgroups of four waves leave every SIMD with one latency-bound wave.  Not kept.)
-static hipError_t launch_mha_fwd_train(const float* qkv, int ld, float* out, int ldo, int B, int Q, int Hd, int Dd, int dh, float scale, float p,
-                                       unsigned long long key, hipStream_t s) {
-  hipLaunchKernelGGL(mha_fwd_train_kernel, dim3((unsigned)(((long)B * Hd * Q + 3) / 4)), dim3(256), 0, s, qkv, ld, out, ldo, B, Q, Hd, Dd, dh, scale, p, key);
-  return hipGetLastError();
+// batched product over z = (image, head); operands are strided views: per-image stride, per-head stride
+GemmF32X mha_gemm(const float* A, int lda, long long a_sb, long long a_sh, bool a_km, const float* W, int ldw, long long w_sb, long long w_sh, bool w_km,
+                  float* C, int ldc, long long c_sb, long long c_sh, int M, int N, int K, int B, int Hd, float alpha) {
+  GemmF32X g; memset(&g, 0, sizeof g);
+  g.A = A; g.lda = lda; g.a_sb = a_sb; g.a_sh = a_sh; g.a_kmajor = a_km;
+  g.W = W; g.ldw = ldw; g.w_sb = w_sb; g.w_sh = w_sh; g.w_kmajor = w_km;
+  g.C = C; g.ldc = ldc; g.c_sb = c_sb; g.c_sh = c_sh;
+  g.M = M; g.N = N; g.K = K; g.batch = B * Hd; g.hb = Hd; g.alpha = alpha; g.ksplit = 1;
+  return g;
 }
-static hipError_t launch_mha_bwd(const float* qkv, int ld, const float* dO, int ldo, float* dqkv, float* dS, float* Pd, int B, int Q, int Hd, int Dd,
-                                 int dh, float scale, float p, unsigned long long key, hipStream_t s) {
-  const unsigned nb = (unsigned)(((long)B * Hd * Q + 3) / 4);
-  hipLaunchKernelGGL(mha_bwd_row_kernel, dim3(nb), dim3(256), 0, s, qkv, ld, dO, ldo, dqkv, dS, Pd, B, Q, Hd, Dd, dh, scale, p, key);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(mha_bwd_col_kernel, dim3(nb), dim3(256), 0, s, qkv, ld, dO, ldo, dqkv, dS, Pd, B, Q, Hd, Dd, dh, scale);
-  return hipGetLastError();
+inline size_t mha_scratch_floats(int B, int Hd, int Q) { return (size_t)B * Hd * Q * up4((size_t)Q); }
+
+// S: [B*Hd, Q, Qp] scratch
+static int launch_mha_fwd_train(const float* qkv, int ld, float* out, int ldo, float* S, int B, int Q, int Hd, int Dd, int dh, float scale, float p,
+                                unsigned long long key, hipStream_t s) {
+  const int Qp = (int)up4((size_t)Q);
+  const long long qs = (long long)Q * ld, ss = (long long)Q * Qp;
+  int rc = launch_gemm_f32x(mha_gemm(qkv, ld, qs, dh, false, qkv + Dd, ld, qs, dh, false, S, Qp, ss * Hd, ss, Q, Q, dh, B, Hd, scale), s);
+  if (rc) return rc;
+  const long nrows = (long)B * Hd * Q;
+  hipLaunchKernelGGL(mha_softmax_fwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, S, Q, Qp, nrows, p, key);
+  if (hipGetLastError() != hipSuccess) return 3;
+  return launch_gemm_f32x(mha_gemm(S, Qp, ss * Hd, ss, false, qkv + 2 * Dd, ld, qs, dh, true, out, ldo, (long long)Q * ldo, dh, Q, dh, Q, B, Hd, 1.0f), s);
+}
+// dS, Pd: [B*Hd, Q, Qp] scratch
+static int launch_mha_bwd(const float* qkv, int ld, const float* dO, int ldo, float* dqkv, float* dS, float* Pd, int B, int Q, int Hd, int Dd,
+                          int dh, float scale, float p, unsigned long long key, hipStream_t s) {
+  const int Qp = (int)up4((size_t)Q);
+  const long long qs = (long long)Q * ld, os = (long long)Q * ldo, ss = (long long)Q * Qp;
+  int rc = launch_gemm_f32x(mha_gemm(qkv, ld, qs, dh, false, qkv + Dd, ld, qs, dh, false, Pd, Qp, ss * Hd, ss, Q, Q, dh, B, Hd, scale), s);
+  if (rc) return rc;
+  rc = launch_gemm_f32x(mha_gemm(dO, ldo, os, dh, false, qkv + 2 * Dd, ld, qs, dh, false, dS, Qp, ss * Hd, ss, Q, Q, dh, B, Hd, 1.0f), s);
+  if (rc) return rc;
+  const long nrows = (long)B * Hd * Q;
+  hipLaunchKernelGGL(mha_softmax_bwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, Pd, dS, Q, Qp, nrows, p, key);
+  if (hipGetLastError() != hipSuccess) return 3;
+  // dq = scale dS k;  dk = scale dS^T q;  dv = Pd^T dO      (k, q, dO enter as the k-major operand: [token, dh] views)
+  rc = launch_gemm_f32x(mha_gemm(dS, Qp, ss * Hd, ss, false, qkv + Dd, ld, qs, dh, true, dqkv, ld, qs, dh, Q, dh, Q, B, Hd, scale), s);
+  if (rc) return rc;
+  rc = launch_gemm_f32x(mha_gemm(dS, Qp, ss * Hd, ss, true, qkv, ld, qs, dh, true, dqkv + Dd, ld, qs, dh, Q, dh, Q, B, Hd, scale), s);
+  if (rc) return rc;
+  return launch_gemm_f32x(mha_gemm(Pd, Qp, ss * Hd, ss, true, dO, ldo, os, dh, true, dqkv + 2 * Dd, ld, qs, dh, Q, dh, Q, B, Hd, 1.0f), s);
 }
 
 // ------------------------------------------------------------------------------------------------ deformable gather backward
@@ -487,26 +428,19 @@ size_t carve_tape(const Dims& d, void* base, Tape* t) {
 struct Scratch {
   float *y, *cat_w, *cat_b;                       // forward: branch output, fused [ref | offsets | weights] linear
   // backward
-  float *dtgt, *dt, *dbr, *dbig, *dproj, *dcat_w, *dcat_b, *dqkv, *dS, *Pd, *dvalues, *dhb, *dz, *padY, *tY, *tX, *wT;
+  float *dtgt, *dt, *dbr, *dbig, *dproj, *dcat_w, *dcat_b, *dqkv, *dS, *Pd, *dvalues, *dhb, *dz;
 };
 size_t carve_scratch(const Dims& d, void* base, Scratch* sc) {
   size_t off = 0;
   auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr; off += al256(n * 4); return p; };
   const size_t BQ = d.BQ, Dd = d.Dd, F = d.F, M = d.M;
   const size_t maxcols = (size_t)(3 * Dd > F ? 3 * Dd : F);           // widest activation of the query side
-  const size_t rows_max = M > BQ ? M : BQ;
   Scratch s;
   s.y = take(BQ * maxcols); s.cat_w = take((size_t)d.ncp * Dd); s.cat_b = take(d.ncp);
   s.dtgt = take(BQ * Dd); s.dt = take(BQ * Dd); s.dbr = take(BQ * Dd); s.dbig = take(BQ * maxcols); s.dproj = take(BQ * d.ncp);
   s.dcat_w = take((size_t)d.ncp * Dd); s.dcat_b = take(d.ncp); s.dqkv = take(BQ * 3 * Dd);
-  s.dS = take((size_t)d.B * d.Hd * d.Q * d.Q); s.Pd = take((size_t)d.B * d.Hd * d.Q * d.Q);
+  s.dS = take(mha_scratch_floats(d.B, d.Hd, d.Q)); s.Pd = take(mha_scratch_floats(d.B, d.Hd, d.Q));
   s.dvalues = take(M * Dd); s.dhb = take(BQ * (Dd / 2)); s.dz = take(BQ * 4);
-  s.padY = take(BQ * up4((size_t)(d.C > d.ncp ? d.C : d.ncp)));
-  const size_t tsz = maxcols * up4(BQ) > Dd * up4(M) ? maxcols * up4(BQ) : Dd * up4(M);     // transposed [features, rows padded to 4]
-  (void)rows_max;
-  s.tY = take(tsz);
-  s.tX = take(tsz);
-  s.wT = take(maxcols * Dd + 64);
   if (sc) *sc = s;
   return off;
 }
@@ -520,23 +454,29 @@ GemmEpi gepi(const float* bias, float* out, int ldc, int act = ACT_NONE, const f
 int lin_fwd(const float* X, int ldx, const float* W, const float* b, int M, int N, int K, float* Y, int ldy, int act, hipStream_t s) {
   return launch_gemm_f32(X, ldx, W, K, M, N, K, gepi(b, Y, ldy, act), s);
 }
-// dX[M,K] (+)= dY[M,N] W[N,K]       (N, ldy arbitrary: padded copies)
-int lin_bwd_x(const float* dY, int ldy, const float* W, int M, int N, int K, float* dX, bool accumulate, const Scratch& sc, hipStream_t s) {
-  const int Np = (int)up4(N);
-  const float* A = dY; int lda = ldy;
-  if (N != Np || ldy % 4) {
-    if (launch_copy2d(dY, ldy, sc.padY, Np, M, N, Np, s)) return 3;
-    A = sc.padY; lda = Np;
-  }
-  if (transpose_pad(W, K, N, K, sc.wT, Np, s)) return 3;              // wT [K, Np] = W^T, pad columns zero
-  return launch_gemm_f32(A, lda, sc.wT, Np, M, K, Np, gepi(nullptr, dX, K, ACT_NONE, accumulate ? dX : nullptr, K), s);
+GemmF32X xgemm(const float* A, int lda, bool a_km, const float* W, int ldw, bool w_km, float* C, int ldc, int M, int N, int K, float alpha, bool accumulate) {
+  GemmF32X g; memset(&g, 0, sizeof g);
+  g.A = A; g.lda = lda; g.a_kmajor = a_km; g.W = W; g.ldw = ldw; g.w_kmajor = w_km; g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.batch = 1; g.hb = 1; g.alpha = alpha; g.accumulate = accumulate; g.ksplit = 1;
+  return g;
+}
+// dX[M,K] (+)= dY[M,N] W[N,K]: W [N, K] is the k-major operand of the product over n
+int lin_bwd_x(const float* dY, int ldy, const float* W, int M, int N, int K, float* dX, bool accumulate, hipStream_t s) {
+  return launch_gemm_f32x(xgemm(dY, ldy, false, W, K, true, dX, K, M, K, N, 1.0f, accumulate), s);
+}
+// C[R,Cc] += alpha * Y[M,R]^T X[M,Cc]: both operands k-major over the M rows.  A small output (weight gradients: a few dozen to
+// a few hundred tiles against a reduction over thousands of rows) splits the rows over grid.z and accumulates atomically.
+int gemm_tn_acc(const float* Y, int ldy, const float* X, int ldx, int M, int R, int Cc, float* C, int ldc, float alpha, hipStream_t s) {
+  GemmF32X g = xgemm(Y, ldy, true, X, ldx, true, C, ldc, R, Cc, M, alpha, true);
+  const int tiles = ((R + 63) / 64) * ((Cc + 63) / 64), nkt = (M + 15) / 16;
+  int ks = 1;
+  if (tiles < 512) { ks = (768 + tiles - 1) / tiles; const int cap = nkt / 8 > 1 ? nkt / 8 : 1; if (ks > cap) ks = cap; }
+  g.ksplit = ks;
+  return launch_gemm_f32x(g, s);
 }
 // dW[N,K] += dY[M,N]^T X[M,K];  db[N] += colsum(dY)
-int lin_bwd_w(const float* dY, int ldy, const float* X, int ldx, int M, int N, int K, float* dW, float* db, const Scratch& sc, hipStream_t s) {
-  const int Mp = (int)up4(M);
-  if (transpose_pad(dY, ldy, M, N, sc.tY, Mp, s)) return 3;           // [N, Mp]
-  if (transpose_pad(X, ldx, M, K, sc.tX, Mp, s)) return 3;            // [K, Mp]
-  int r = launch_gemm_f32(sc.tY, Mp, sc.tX, Mp, N, K, Mp, gepi(nullptr, dW, K, ACT_NONE, dW, K), s);
+int lin_bwd_w(const float* dY, int ldy, const float* X, int ldx, int M, int N, int K, float* dW, float* db, hipStream_t s) {
+  int r = gemm_tn_acc(dY, ldy, X, ldx, M, N, K, dW, K, 1.0f, s);
   if (r) return r;
   return db ? colsum_add(dY, ldy, M, N, db, s) : 0;
 }
@@ -589,7 +529,7 @@ int dod_decoder_train_forward(const dod_config* cfg, const dod_dec_train_params*
   for (int j = 0; j < d.L; ++j) {
     auto& L = t.l[j];
     TK(lin_fwd(L.tgt_in, Dd, p->in_proj_w, p->in_proj_b, BQ, 3 * Dd, Dd, L.qkv, 3 * Dd, ACT_NONE, s));
-    TH(launch_mha_fwd_train(L.qkv, 3 * Dd, L.att, Dd, B, Q, d.Hd, Dd, d.dh, scale, dropout_p, site_key(seed, j, 0), s));
+    TK(launch_mha_fwd_train(L.qkv, 3 * Dd, L.att, Dd, sc.Pd, B, Q, d.Hd, Dd, d.dh, scale, dropout_p, site_key(seed, j, 0), s));
     TK(lin_fwd(L.att, Dd, p->out_proj_w, p->out_proj_b, BQ, Dd, Dd, sc.y, Dd, ACT_NONE, s));
     TK(dropout_add(L.tgt_in, sc.y, L.t1, (size_t)BQ * Dd, dropout_p, site_key(seed, j, 1), s));
     TK(launch_layernorm(L.t1, nullptr, p->norm1_w, p->norm1_b, cfg->dec_ln_eps, BQ, Dd, L.tgt1, nullptr, s));
@@ -640,17 +580,17 @@ int dod_decoder_train_backward(const dod_config* cfg, const dod_dec_train_params
   // ---- heads (detr_decoder.py:80-81; utils.py:14-30)
   hipLaunchKernelGGL(sigmoid_bwd4_kernel, dim3((BQ * 4 + 255) / 256), dim3(256), 0, s, d_det + C, C + 4, t.boxes, 4, sc.dz, BQ);
   TH(hipGetLastError());
-  TK(lin_bwd_w(sc.dz, 4, t.hb, Dd / 2, BQ, 4, Dd / 2, G(grads->bb2_w), G(grads->bb2_b), sc, s));
-  TK(lin_bwd_x(sc.dz, 4, p->bb2_w, BQ, 4, Dd / 2, sc.dhb, false, sc, s));
+  TK(lin_bwd_w(sc.dz, 4, t.hb, Dd / 2, BQ, 4, Dd / 2, G(grads->bb2_w), G(grads->bb2_b), s));
+  TK(lin_bwd_x(sc.dz, 4, p->bb2_w, BQ, 4, Dd / 2, sc.dhb, false, s));
   {
     const size_t n = (size_t)BQ * (Dd / 2);
     hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, sc.dhb, t.hb, sc.dhb, n, 0.f, 0ull);
     TH(hipGetLastError());
   }
-  TK(lin_bwd_w(sc.dhb, Dd / 2, t.hs, Dd, BQ, Dd / 2, Dd, G(grads->bb0_w), G(grads->bb0_b), sc, s));
-  TK(lin_bwd_x(sc.dhb, Dd / 2, p->bb0_w, BQ, Dd / 2, Dd, sc.dtgt, false, sc, s));
-  TK(lin_bwd_w(d_det, C + 4, t.hs, Dd, BQ, C, Dd, G(grads->class_w), G(grads->class_b), sc, s));
-  TK(lin_bwd_x(d_det, C + 4, p->class_w, BQ, C, Dd, sc.dtgt, true, sc, s));
+  TK(lin_bwd_w(sc.dhb, Dd / 2, t.hs, Dd, BQ, Dd / 2, Dd, G(grads->bb0_w), G(grads->bb0_b), s));
+  TK(lin_bwd_x(sc.dhb, Dd / 2, p->bb0_w, BQ, Dd / 2, Dd, sc.dtgt, false, s));
+  TK(lin_bwd_w(d_det, C + 4, t.hs, Dd, BQ, C, Dd, G(grads->class_w), G(grads->class_b), s));
+  TK(lin_bwd_x(d_det, C + 4, p->class_w, BQ, C, Dd, sc.dtgt, true, s));
   // ---- layers, last to first (weights tied: every layer adds into the same gradient tensors)
   for (int j = d.L - 1; j >= 0; --j) {
     const auto& L = t.l[j];
@@ -659,35 +599,35 @@ int dod_decoder_train_backward(const dod_config* cfg, const dod_dec_train_params
     TK(dropout_add(nullptr, sc.dt, sc.dbr, nBD, dropout_p, site_key(seed, j, 4), s));                       // d(linear2 output)
     const float* hin = L.hid;
     if (dropout_p > 0.f) { TK(dropout_add(nullptr, L.hid, sc.y, (size_t)BQ * F, dropout_p, site_key(seed, j, 3), s)); hin = sc.y; }
-    TK(lin_bwd_w(sc.dbr, Dd, hin, F, BQ, Dd, F, G(grads->lin2_w), G(grads->lin2_b), sc, s));
-    TK(lin_bwd_x(sc.dbr, Dd, p->lin2_w, BQ, Dd, F, sc.dbig, false, sc, s));
+    TK(lin_bwd_w(sc.dbr, Dd, hin, F, BQ, Dd, F, G(grads->lin2_w), G(grads->lin2_b), s));
+    TK(lin_bwd_x(sc.dbr, Dd, p->lin2_w, BQ, Dd, F, sc.dbig, false, s));
     {
       const size_t n = (size_t)BQ * F;
       hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, sc.dbig, L.hid, sc.dbig, n,
                          dropout_p, site_key(seed, j, 3));
       TH(hipGetLastError());
     }
-    TK(lin_bwd_w(sc.dbig, F, L.tgt2, Dd, BQ, F, Dd, G(grads->lin1_w), G(grads->lin1_b), sc, s));
-    TK(lin_bwd_x(sc.dbig, F, p->lin1_w, BQ, F, Dd, sc.dt, true, sc, s));                                   // dt = d(tgt2): residual + FFN input
+    TK(lin_bwd_w(sc.dbig, F, L.tgt2, Dd, BQ, F, Dd, G(grads->lin1_w), G(grads->lin1_b), s));
+    TK(lin_bwd_x(sc.dbig, F, p->lin1_w, BQ, F, Dd, sc.dt, true, s));                                   // dt = d(tgt2): residual + FFN input
     // LN2 <- tgt1 + dropout2(output_proj(samp))
     TK(ln_bwd(L.t2, p->norm2_w, sc.dt, cfg->dec_ln_eps, BQ, Dd, sc.dtgt, G(grads->norm2_w), G(grads->norm2_b), s));   // dtgt = d(t2)
     TK(dropout_add(nullptr, sc.dtgt, sc.dbr, nBD, dropout_p, site_key(seed, j, 2), s));
-    TK(lin_bwd_w(sc.dbr, Dd, L.samp, Dd, BQ, Dd, Dd, G(grads->op_w), G(grads->op_b), sc, s));
-    TK(lin_bwd_x(sc.dbr, Dd, p->op_w, BQ, Dd, Dd, sc.dt, false, sc, s));                                   // dt = d(samp)
+    TK(lin_bwd_w(sc.dbr, Dd, L.samp, Dd, BQ, Dd, Dd, G(grads->op_w), G(grads->op_b), s));
+    TK(lin_bwd_x(sc.dbr, Dd, p->op_w, BQ, Dd, Dd, sc.dt, false, s));                                   // dt = d(samp)
     TH(hipMemsetAsync(sc.dproj, 0, (size_t)BQ * d.ncp * 4, s));
     hipLaunchKernelGGL(deform_bwd_kernel, dim3((unsigned)(((long)BQ * d.Hd + 3) / 4)), dim3(256), 0, s, L.proj, d.ncp, t.values, sc.dt, B, Q, N, d.Hd, d.P,
                        d.dh, d.fh, d.fw, sc.dproj, sc.dvalues);
     TH(hipGetLastError());
-    TK(lin_bwd_w(sc.dproj, d.ncp, L.tgt1, Dd, BQ, d.ncat, Dd, sc.dcat_w, sc.dcat_b, sc, s));
-    TK(lin_bwd_x(sc.dproj, d.ncp, sc.cat_w, BQ, d.ncat, Dd, sc.dtgt, true, sc, s));                        // dtgt = d(tgt1)
+    TK(lin_bwd_w(sc.dproj, d.ncp, L.tgt1, Dd, BQ, d.ncat, Dd, sc.dcat_w, sc.dcat_b, s));
+    TK(lin_bwd_x(sc.dproj, d.ncp, sc.cat_w, BQ, d.ncat, Dd, sc.dtgt, true, s));                        // dtgt = d(tgt1)
     // LN1 <- tgt_in + dropout1(out_proj(att))
     TK(ln_bwd(L.t1, p->norm1_w, sc.dtgt, cfg->dec_ln_eps, BQ, Dd, sc.dt, G(grads->norm1_w), G(grads->norm1_b), s));   // dt = d(t1)
     TK(dropout_add(nullptr, sc.dt, sc.dbr, nBD, dropout_p, site_key(seed, j, 1), s));
-    TK(lin_bwd_w(sc.dbr, Dd, L.att, Dd, BQ, Dd, Dd, G(grads->out_proj_w), G(grads->out_proj_b), sc, s));
-    TK(lin_bwd_x(sc.dbr, Dd, p->out_proj_w, BQ, Dd, Dd, sc.dtgt, false, sc, s));                           // dtgt = d(att)
-    TH(launch_mha_bwd(L.qkv, 3 * Dd, sc.dtgt, Dd, sc.dqkv, sc.dS, sc.Pd, B, Q, d.Hd, Dd, d.dh, scale, dropout_p, site_key(seed, j, 0), s));
-    TK(lin_bwd_w(sc.dqkv, 3 * Dd, L.tgt_in, Dd, BQ, 3 * Dd, Dd, G(grads->in_proj_w), G(grads->in_proj_b), sc, s));
-    TK(lin_bwd_x(sc.dqkv, 3 * Dd, p->in_proj_w, BQ, 3 * Dd, Dd, sc.dt, true, sc, s));                      // dt = d(tgt_in): next (earlier) layer's d(output)
+    TK(lin_bwd_w(sc.dbr, Dd, L.att, Dd, BQ, Dd, Dd, G(grads->out_proj_w), G(grads->out_proj_b), s));
+    TK(lin_bwd_x(sc.dbr, Dd, p->out_proj_w, BQ, Dd, Dd, sc.dtgt, false, s));                           // dtgt = d(att)
+    TK(launch_mha_bwd(L.qkv, 3 * Dd, sc.dtgt, Dd, sc.dqkv, sc.dS, sc.Pd, B, Q, d.Hd, Dd, d.dh, scale, dropout_p, site_key(seed, j, 0), s));
+    TK(lin_bwd_w(sc.dqkv, 3 * Dd, L.tgt_in, Dd, BQ, 3 * Dd, Dd, G(grads->in_proj_w), G(grads->in_proj_b), s));
+    TK(lin_bwd_x(sc.dqkv, 3 * Dd, p->in_proj_w, BQ, 3 * Dd, Dd, sc.dt, true, s));                      // dt = d(tgt_in): next (earlier) layer's d(output)
     TH(hipMemcpyAsync(sc.dtgt, sc.dt, nBD * 4, hipMemcpyDeviceToDevice, s));
   }
   // query embedding: tgt_0[b] = query_embed for every image (detr_decoder.py:59)
@@ -704,8 +644,8 @@ int dod_decoder_train_backward(const dod_config* cfg, const dod_dec_train_params
     TK(add_inplace(G(grads->aw_b), dbv + 2 + HP * 2, (size_t)HP, s));
   }
   // value projection (computed once for the tied layers: d(values) is the sum over layers)
-  TK(lin_bwd_w(sc.dvalues, Dd, memory, Dd, d.M, Dd, Dd, G(grads->vp_w), G(grads->vp_b), sc, s));
-  if (d_memory) TK(lin_bwd_x(sc.dvalues, Dd, p->vp_w, d.M, Dd, Dd, d_memory, false, sc, s));
+  TK(lin_bwd_w(sc.dvalues, Dd, memory, Dd, d.M, Dd, Dd, G(grads->vp_w), G(grads->vp_b), s));
+  if (d_memory) TK(lin_bwd_x(sc.dvalues, Dd, p->vp_w, d.M, Dd, Dd, d_memory, false, s));
   return DOD_OK;
 }
 
@@ -750,39 +690,98 @@ size_t carve_ttape(const TDims& d, void* base, TTape* t) {
   if (t) *t = tt;
   return off;
 }
-struct TScratch { float *dx, *da, *db, *dbig, *dqkv, *dS, *Pd, *T, *U, *avec, *dump, *tY, *tX, *wT, *padY; };
+struct TScratch { float *dx, *da, *db, *dbig, *dqkv, *dS, *Pd, *T, *U, *dump; };
 size_t carve_tscratch(const TDims& d, void* base, TScratch* sc) {
   size_t off = 0;
   auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr; off += al256(n * 4); return p; };
   const size_t M = d.M, D = d.D, F = d.F, big = F > 3 * D ? F : 3 * D;
   TScratch s;
   s.dx = take(M * D); s.da = take(M * D); s.db = take(M * D); s.dbig = take(M * big); s.dqkv = take(M * 3 * D);
-  s.dS = take((size_t)d.B * d.H * d.N * d.N); s.Pd = take((size_t)d.B * d.H * d.N * d.N);
-  s.T = take(M * up4(d.r)); s.U = take(M * up4(d.r)); s.avec = take(64); s.dump = take(2 * big);
-  s.tY = take(big * up4(M)); s.tX = take(big * up4(M)); s.wT = take(big * D + 64); s.padY = take(M * up4(d.r) + 64);
+  s.dS = take(mha_scratch_floats(d.B, d.H, d.N)); s.Pd = take(mha_scratch_floats(d.B, d.H, d.N));
+  s.T = take(M * up4(d.r)); s.U = take(M * up4(d.r)); s.dump = take(2 * big);
   if (sc) *sc = s;
   return off;
 }
-// the generic linear backward helpers take a Scratch: view a TScratch as one
-Scratch as_scratch(const TScratch& t) { Scratch s; memset(&s, 0, sizeof s); s.tY = t.tY; s.tX = t.tX; s.wT = t.wT; s.padY = t.padY; return s; }
+// Rank-r products of a LoRA pair, r <= 8 (the reference trains r = 2: dinov2_backbone.py:47-51): both are bound by reading the
+// [M, features] activation once, which a 64x64-tile GEMM with r useful columns cannot do (12 workgroups walking 4 112 rows: 115 us).
+//   down: T[m, c] = alpha * sum_k X[m, k] * A(c, k)            one wave per row, lanes along k;   A(c, k) = A[c * sa_c + k * sa_k]
+//   up  : G(o, c) += sum_m Y[m, o] * T[m, c]                   one thread per column o, 64 rows per workgroup, atomic accumulate
+#define LORA_RMAX 8
+#define LORA_UP_ROWS 64
+__global__ __launch_bounds__(256) void lora_down_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ A, int sa_c, int sa_k, int M, int K,
+                                                        int r, float alpha, float* __restrict__ T, int ldt) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* x = X + (size_t)m * ldx;
+  float acc[LORA_RMAX];
+#pragma unroll
+  for (int c = 0; c < LORA_RMAX; ++c) acc[c] = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float xv = x[k];
+    const float* ak = A + (size_t)k * sa_k;
+#pragma unroll
+    for (int c = 0; c < LORA_RMAX; ++c)
+      if (c < r) acc[c] = fmaf(xv, ak[(size_t)c * sa_c], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < LORA_RMAX; ++c) {
+    if (c < r) {
+      const float v = wave_sum(acc[c]);
+      if (lane == 0) T[(size_t)m * ldt + c] = alpha * v;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void lora_up_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ T, int ldt, int M, int O, int r,
+                                                      float* __restrict__ G, int sg_o, int sg_c) {
+  __shared__ float sT[LORA_UP_ROWS][LORA_RMAX];
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int m0 = blockIdx.y * LORA_UP_ROWS;
+  const int nm = M - m0 < LORA_UP_ROWS ? M - m0 : LORA_UP_ROWS;
+  for (int i = threadIdx.x; i < LORA_UP_ROWS * LORA_RMAX; i += 256) {
+    const int mm = i / LORA_RMAX, c = i % LORA_RMAX;
+    sT[mm][c] = (mm < nm && c < r) ? T[(size_t)(m0 + mm) * ldt + c] : 0.f;
+  }
+  __syncthreads();
+  if (o >= O) return;
+  float acc[LORA_RMAX];
+#pragma unroll
+  for (int c = 0; c < LORA_RMAX; ++c) acc[c] = 0.f;
+  const float* y = Y + (size_t)m0 * ldy + o;
+  for (int mm = 0; mm < nm; ++mm) {
+    const float yv = y[(size_t)mm * ldy];
+#pragma unroll
+    for (int c = 0; c < LORA_RMAX; ++c) acc[c] = fmaf(yv, sT[mm][c], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < LORA_RMAX; ++c)
+    if (c < r) unsafeAtomicAdd(G + (size_t)o * sg_o + (size_t)c * sg_c, acc[c]);
+}
+int lora_down(const float* X, int ldx, const float* A, int sa_c, int sa_k, int M, int K, int r, float alpha, float* T, int ldt, hipStream_t s) {
+  hipLaunchKernelGGL(lora_down_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, ldx, A, sa_c, sa_k, M, K, r, alpha, T, ldt);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+int lora_up(const float* Y, int ldy, const float* T, int ldt, int M, int O, int r, float* G, int sg_o, int sg_c, hipStream_t s) {
+  hipLaunchKernelGGL(lora_up_kernel, dim3((O + 255) / 256, (M + LORA_UP_ROWS - 1) / LORA_UP_ROWS), dim3(256), 0, s, Y, ldy, T, ldt, M, O, r, G, sg_o, sg_c);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
 
 // gradients of one LoRA pair for out = X W'^T: dB [out, r] += alpha dY^T (X A^T), dA [r, in] += alpha (dY B)^T X
 int lora_grads(const TDims& d, const float* X, int in_f, const float* dY, int ldy, int out_f, const float* A, const float* Bm, float* dA, float* dB,
                const TScratch& t, hipStream_t s) {
   if (!dA || !dB) return 0;
-  const Scratch sc = as_scratch(t);
-  const int r = d.r, rp = (int)up4(r);
-  GemmEpi e = gepi(nullptr, t.T, rp); e.scale = t.avec;                                   // T = alpha X A^T   [M, r]
-  int rc = launch_gemm_f32(X, in_f, A, in_f, d.M, r, in_f, e, s); if (rc) return rc;
-  rc = lin_bwd_w(dY, ldy, t.T, rp, d.M, out_f, r, dB, nullptr, sc, s); if (rc) return rc;  // dB += dY^T T
-  {                                                                                       // U = alpha dY B   [M, r]
-    const int Np = (int)up4(out_f);
-    if (out_f != Np || ldy % 4) return 2;
-    if (transpose_pad(Bm, r, out_f, r, sc.wT, Np, s)) return 3;                           // B^T [r, out]
-    GemmEpi eu = gepi(nullptr, t.U, rp); eu.scale = t.avec;
-    rc = launch_gemm_f32(dY, ldy, sc.wT, Np, d.M, r, Np, eu, s); if (rc) return rc;
+  const int r = d.r, rp = (int)up4(r), M = d.M;
+  int rc;
+  if (r <= LORA_RMAX) {
+    rc = lora_down(X, in_f, A, in_f, 1, M, in_f, r, d.alpha, t.T, rp, s); if (rc) return rc;            // T = alpha X A^T   [M, r]
+    rc = lora_up(dY, ldy, t.T, rp, M, out_f, r, dB, r, 1, s); if (rc) return rc;                        // dB += dY^T T
+    rc = lora_down(dY, ldy, Bm, 1, r, M, out_f, r, d.alpha, t.U, rp, s); if (rc) return rc;             // U = alpha dY B    [M, r]
+    return lora_up(X, in_f, t.U, rp, M, in_f, r, dA, 1, in_f, s);                                       // dA += U^T X
   }
-  return lin_bwd_w(t.U, rp, X, in_f, d.M, r, in_f, dA, nullptr, sc, s);                    // dA += U^T X
+  rc = launch_gemm_f32x(xgemm(X, in_f, false, A, in_f, false, t.T, rp, M, r, in_f, d.alpha, false), s); if (rc) return rc;
+  rc = gemm_tn_acc(dY, ldy, t.T, rp, M, out_f, r, dB, r, 1.0f, s); if (rc) return rc;
+  rc = launch_gemm_f32x(xgemm(dY, ldy, false, Bm, r, true, t.U, rp, M, r, out_f, d.alpha, false), s); if (rc) return rc;
+  return gemm_tn_acc(t.U, rp, X, in_f, M, r, in_f, dA, in_f, 1.0f, s);
 }
 
 }  // namespace
@@ -871,18 +870,15 @@ int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_pa
   TTape t; TScratch sc;
   carve_ttape(d, (void*)(((uintptr_t)tape + 255) & ~(uintptr_t)255), &t);
   carve_tscratch(d, (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &sc);
-  const Scratch gs = as_scratch(sc);
   auto G = [](const float* q) { return const_cast<float*>(q); };
   const int M = d.M, D = d.D, F = d.F;
   const size_t nMD = (size_t)M * D;
   const float scale = 1.0f / sqrtf((float)d.dh);
-  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, s, sc.avec, d.alpha, 64);
-  TH(hipGetLastError());
   auto blocks_for = [](size_t n) { return dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)); };
   // ---- projection + final LayerNorm (frozen affine: its parameter gradients go to a dump)
   if (cfg->target_dim) {
-    TK(lin_bwd_w(d_mem, d.Dd, t.f, D, M, d.Dd, D, G(grads->proj_w), G(grads->proj_b), gs, s));
-    TK(lin_bwd_x(d_mem, d.Dd, p->proj_w, M, d.Dd, D, sc.da, false, gs, s));
+    TK(lin_bwd_w(d_mem, d.Dd, t.f, D, M, d.Dd, D, G(grads->proj_w), G(grads->proj_b), s));
+    TK(lin_bwd_x(d_mem, d.Dd, p->proj_w, M, d.Dd, D, sc.da, false, s));
     TK(ln_bwd(t.xout, p->lnf_w, sc.da, d.eps, M, D, sc.dx, sc.dump, sc.dump + D, s));
   } else {
     TK(ln_bwd(t.xout, p->lnf_w, d_mem, d.eps, M, D, sc.dx, sc.dump, sc.dump + D, s));
@@ -896,25 +892,25 @@ int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_pa
     hipLaunchKernelGGL(colscale_kernel, blocks_for(nMD), dim3(256), 0, s, sc.dx, bp.ls2, sc.da, nMD, D);                  // da = d(fc2 out)
     TH(hipGetLastError());
     TK(lora_grads(d, tb.h, F, sc.da, D, D, bp.fc2.A, bp.fc2.Bm, G(gp.fc2.A), G(gp.fc2.Bm), sc, s));
-    TK(lin_bwd_x(sc.da, D, tb.W2, M, D, F, sc.dbig, false, gs, s));                                                       // d(h)
+    TK(lin_bwd_x(sc.da, D, tb.W2, M, D, F, sc.dbig, false, s));                                                       // d(h)
     hipLaunchKernelGGL(gelu_bwd_kernel, blocks_for((size_t)M * F), dim3(256), 0, s, sc.dbig, tb.pre, sc.dbig, (size_t)M * F);
     TH(hipGetLastError());
     TK(lora_grads(d, tb.y2, D, sc.dbig, F, F, bp.fc1.A, bp.fc1.Bm, G(gp.fc1.A), G(gp.fc1.Bm), sc, s));
-    TK(lin_bwd_x(sc.dbig, F, tb.W1, M, F, D, sc.da, false, gs, s));                                                       // d(y2)
+    TK(lin_bwd_x(sc.dbig, F, tb.W1, M, F, D, sc.da, false, s));                                                       // d(y2)
     TK(ln_bwd(tb.x1, bp.ln2_w, sc.da, d.eps, M, D, sc.db, sc.dump, sc.dump + D, s));
     TK(add_inplace(sc.dx, sc.db, nMD, s));                                                                                // dx = d(x1)
     // x1 = x + ls1 * (ctx Wo'^T + bo)
     hipLaunchKernelGGL(colscale_kernel, blocks_for(nMD), dim3(256), 0, s, sc.dx, bp.ls1, sc.da, nMD, D);
     TH(hipGetLastError());
     TK(lora_grads(d, tb.ctx, D, sc.da, D, D, bp.o.A, bp.o.Bm, G(gp.o.A), G(gp.o.Bm), sc, s));
-    TK(lin_bwd_x(sc.da, D, tb.Wo, M, D, D, sc.db, false, gs, s));                                                         // db = d(ctx)
-    TH(launch_mha_bwd(tb.qkv, 3 * D, sc.db, D, sc.dqkv, sc.dS, sc.Pd, B, N, d.H, D, d.dh, scale, 0.f, 0ull, s));
+    TK(lin_bwd_x(sc.da, D, tb.Wo, M, D, D, sc.db, false, s));                                                         // db = d(ctx)
+    TK(launch_mha_bwd(tb.qkv, 3 * D, sc.db, D, sc.dqkv, sc.dS, sc.Pd, B, N, d.H, D, d.dh, scale, 0.f, 0ull, s));
     const dod_lora_linear* qkv3[3] = {&bp.q, &bp.k, &bp.v};
     const dod_lora_linear* gqkv3[3] = {&gp.q, &gp.k, &gp.v};
     for (int c = 0; c < 3; ++c)
       TK(lora_grads(d, tb.y1, D, sc.dqkv + (size_t)c * D, 3 * D, D, qkv3[c]->A, qkv3[c]->Bm, G(gqkv3[c]->A), G(gqkv3[c]->Bm), sc, s));
     if (i > 0) {        // the tail's input is the frozen prefix's output: nothing below block 0 needs a gradient
-      TK(lin_bwd_x(sc.dqkv, 3 * D, tb.Wqkv, M, 3 * D, D, sc.da, false, gs, s));                                           // d(y1)
+      TK(lin_bwd_x(sc.dqkv, 3 * D, tb.Wqkv, M, 3 * D, D, sc.da, false, s));                                           // d(y1)
       TK(ln_bwd(tb.x, bp.ln1_w, sc.da, d.eps, M, D, sc.db, sc.dump, sc.dump + D, s));
       TK(add_inplace(sc.dx, sc.db, nMD, s));                                                                              // dx = d(x): the block below's output
     }

@@ -1051,6 +1051,19 @@ int dod_op_linear(int in_dtype, const void* A, int lda, const void* W, int ldw, 
   if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
   return DOD_OK;
 }
+int dod_op_gemm_f32x(const float* A, int lda, int a_kmajor, long long a_sb, long long a_sh, const float* W, int ldw, int w_kmajor, long long w_sb,
+                     long long w_sh, float* C, int ldc, long long c_sb, long long c_sh, int M, int N, int K, int batch, int hb, float alpha,
+                     int accumulate, int ksplit, void* stream) {
+  if (!A || !W || !C) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  GemmF32X g; memset(&g, 0, sizeof g);
+  g.A = A; g.lda = lda; g.a_kmajor = a_kmajor; g.a_sb = a_sb; g.a_sh = a_sh;
+  g.W = W; g.ldw = ldw; g.w_kmajor = w_kmajor; g.w_sb = w_sb; g.w_sh = w_sh;
+  g.C = C; g.ldc = ldc; g.c_sb = c_sb; g.c_sh = c_sh;
+  g.M = M; g.N = N; g.K = K; g.batch = batch; g.hb = hb; g.alpha = alpha; g.accumulate = accumulate; g.ksplit = ksplit;
+  int r = launch_gemm_f32x(g, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_gemm_f32x rejected M=%d N=%d K=%d batch=%d (rc %d)", M, N, K, batch, r);
+  return DOD_OK;
+}
 int dod_op_linear_fp8(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, int M, int N, int K,
                       const float* bias, const float* scale, const float* resid, int ldr, void* out, int out_dtype, int ldc, int act,
                       void* stream) {

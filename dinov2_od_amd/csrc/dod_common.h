@@ -123,6 +123,22 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
                      const GemmEpi& e, hipStream_t s);
 int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K,
                     const GemmEpi& e, hipStream_t s);
+// The same exact-fp32 MFMA main loop for the training step's products (dec_train.hip): either operand may be given k-major
+// ([K, rows]: the transposed products of a backward need no transposed copies), a two-level batch (image, head) walks strided views
+// (attention scores / context / their adjoints as batched GEMMs), the K range may be split over grid.z with an atomic accumulate.
+//   C[z] (+)= alpha * A[z] W[z]^T (+ bias, activation);   z = zb * hb + zh,  X[z] = X + zb * x_sb + zh * x_sh   (strides in floats)
+struct GemmF32X {
+  const float* A; const float* W; float* C; const float* bias;
+  int lda, ldw, ldc, M, N, K;
+  long long a_sb, a_sh, w_sb, w_sh, c_sb, c_sh;
+  int batch, hb;            // batch = number of z, hb = inner (head) count; 1, 1 for a plain product
+  int a_kmajor, w_kmajor;   // operand stored [K, rows] (rows contiguous) instead of [rows, K]
+  float alpha;
+  int accumulate;           // C += instead of C =
+  int act;                  // ACT_* (not with ksplit > 1)
+  int ksplit;               // > 1: K split over grid.z, partial products added atomically (implies accumulate; C must hold the addend)
+};
+int launch_gemm_f32x(const GemmF32X& g, hipStream_t s);
 // fp8 (OCP e4m3) operands, one byte per element, K contiguous; e.a_scale / e.w_scale are the dequant scales
 int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int ldw, int M, int N, int K,
                     const GemmEpi& e, hipStream_t s);

@@ -1,21 +1,130 @@
 // Exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fmaf chain) with the same
 // fused epilogues as the bf16 kernel.  Used for (a) the strict-parity mode of the backbone, the mode
-// gated at 1e-3 against the reference's fp32 CPU forward, and (b) every decoder/head linear in both
+// gated at 1e-3 against the reference's fp32 CPU forward, (b) every decoder/head linear in both
 // modes (K11-K13, K17-K19: deformable_attention.py:86-94,181,232-238,264-266; detr_decoder.py:80-81),
-// whose sampling-coordinate math must stay fp32 (floor() at deformable_attention.py:114-115).
-//   C[M,N] = A[M,K] * W[N,K]^T, arbitrary M, N (guarded), K % 4 == 0.
+// whose sampling-coordinate math must stay fp32 (floor() at deformable_attention.py:114-115), and
+// (c) every product of the native training step (dec_train.hip; train.py:1079-1109).
+//   C[M,N] = A[M,K] * W[N,K]^T, arbitrary M, N, K (guarded).
 // Tile 64x64x16, 256 threads = 4 waves (2x2), one 32x32 accumulator per wave, computed transposed
 // (D = W_tile * A_tile^T) so a lane owns an output row and register quads run along n.
 // LDS holds both operands k-major ([k][row], stride 66 floats) so the one-float-per-lane MFMA operands
 // are conflict-free ds_read_b32 (lanes 0-31 consecutive rows at k, lanes 32-63 at k+1).
+// Global loads run a four-deep register ring ahead of the LDS stage: most of these launches put one or two workgroups on a CU,
+// where a single k-tile in flight left every iteration waiting out a full memory latency (1 600-row decoder linears: 47 us for
+// 1.9 GFLOP before the ring).
 #include "dod_common.h"
 #include <cstdlib>
+#include <cstring>
 
 #define FBM 64
 #define FBN 64
 #define FBK 16
 #define FLD 66   // 4*FLD == 8 (mod 32): the transposing ds_write_b32 pattern below is conflict-free
+#define FPD 4    // k-tiles in flight per thread (register ring)
 
+namespace {
+
+// One operand's 64-row x 16-k tile: global -> registers -> LDS [k][row].
+//   KM = false: stored [rows, K] (k contiguous): thread -> (row = tid / 4, k = 4 * (tid % 4)), transposing LDS write
+//   KM = true : stored [K, rows] (rows contiguous): thread -> (k = tid / 16, row = 4 * (tid % 16)), straight LDS write
+// VEC: base, pitch and batch strides allow aligned float4 loads (the pitch then covers a partial last quad); otherwise four scalar
+// loads.  Both forms are branch-free -- clamped address, value selected to zero -- so the loads of the ring stay in flight
+// across iterations (a divergent branch around a load makes the compiler drain vmcnt at the join).
+template <bool KM, bool VEC>
+struct TileLoad {
+  const float* base; int ld, rows, kend, r0; int a, b;
+  __device__ __forceinline__ void init(const float* base_, int ld_, int rows_, int kend_, int r0_, int tid) {
+    base = base_; ld = ld_; rows = rows_; kend = kend_; r0 = r0_;
+    if (KM) { a = tid >> 4; b = (tid & 15) * 4; } else { a = tid >> 2; b = (tid & 3) * 4; }
+  }
+  __device__ __forceinline__ float4 load(int k0) const {
+    // (o, c): the strided and the contiguous coordinate of this thread's quad; (on, cn): their extents
+    const int o = KM ? k0 + a : r0 + a, c = KM ? r0 + b : k0 + b;
+    const int on = KM ? kend : rows, cn = KM ? rows : kend;
+    const bool oin = o < on;
+    const float* row = base + (size_t)(oin ? o : 0) * ld;
+    float4 v;
+    if (VEC) {
+      v = *reinterpret_cast<const float4*>(row + (c < cn ? c : 0));
+    } else {
+      v.x = row[c < cn ? c : 0]; v.y = row[c + 1 < cn ? c + 1 : 0]; v.z = row[c + 2 < cn ? c + 2 : 0]; v.w = row[c + 3 < cn ? c + 3 : 0];
+    }
+    return v;               // unmasked: store() applies the guards, so nothing consumes the load before the LDS stage needs it
+  }
+  __device__ __forceinline__ void store(float* s, float4 v, int k0) const {
+    const int o = KM ? k0 + a : r0 + a, c = KM ? r0 + b : k0 + b;
+    const int on = KM ? kend : rows, cn = KM ? rows : kend;
+    const bool oin = o < on;
+    v.x = oin && c < cn ? v.x : 0.f; v.y = oin && c + 1 < cn ? v.y : 0.f; v.z = oin && c + 2 < cn ? v.z : 0.f; v.w = oin && c + 3 < cn ? v.w : 0.f;
+    if (KM) {
+      float* d = s + a * FLD + b;                    // 8-byte aligned (FLD even, b % 4 == 0)
+      *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+    } else {
+      float* d = s + b * FLD + a;
+      d[0] = v.x; d[FLD] = v.y; d[2 * FLD] = v.z; d[3 * FLD] = v.w;
+    }
+  }
+};
+
+// acc (32x32 per wave, transposed) over the k-tiles [kt0, kt1) of the (m0, n0) tile
+template <class LA, class LW>
+__device__ __forceinline__ void f32_mainloop(const LA& la, const LW& lw, int kt0, int kt1,
+                                             float (*sA)[FBK * FLD], float (*sW)[FBK * FLD], f32x16& acc) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nk = kt1 - kt0;
+  float4 ra[FPD], rw[FPD];
+  // Tiles past the end load a clamped address and are zeroed at the LDS store: the ring's loop body has no branch around a load,
+  // which is what lets the compiler count vmcnt down instead of draining it (checked in the ISA: vmcnt(6) before each LDS store).
+#pragma unroll
+  for (int p = 0; p < FPD; ++p) { ra[p] = la.load((kt0 + p) * FBK); rw[p] = lw.load((kt0 + p) * FBK); }
+  la.store(sA[0], ra[0], kt0 * FBK);
+  lw.store(sW[0], rw[0], kt0 * FBK);
+  __syncthreads();
+  auto mma = [&](int st) {
+    const float* a = &sA[st][wm * 32 + lr];
+    const float* w = &sW[st][wn * 32 + lr];
+#pragma unroll
+    for (int s = 0; s < FBK / 2; ++s) {
+      const float av = a[(2 * s + lh) * FLD];
+      const float wv = w[(2 * s + lh) * FLD];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc, 0, 0, 0);
+    }
+  };
+  int kt = 0;
+  for (; kt + FPD <= nk; kt += FPD) {             // full groups: tile kt + j sits in LDS stage j & 1 and leaves ring slot j free
+#pragma unroll
+    for (int j = 0; j < FPD; ++j) {
+      ra[j] = la.load((kt0 + kt + j + FPD) * FBK);
+      rw[j] = lw.load((kt0 + kt + j + FPD) * FBK);
+      mma(j & 1);
+      la.store(sA[(j + 1) & 1], ra[(j + 1) % FPD], (kt0 + kt + j + 1) * FBK);
+      lw.store(sW[(j + 1) & 1], rw[(j + 1) % FPD], (kt0 + kt + j + 1) * FBK);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < FPD - 1; ++j) {             // the last nk % FPD tiles are already in the ring
+    if (kt + j < nk) {                            // uniform
+      mma(j & 1);
+      if (kt + j + 1 < nk) {
+        la.store(sA[(j + 1) & 1], ra[j + 1], (kt0 + kt + j + 1) * FBK);
+        lw.store(sW[(j + 1) & 1], rw[j + 1], (kt0 + kt + j + 1) * FBK);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+inline bool vec_ok(const void* p, long long ld, long long s1 = 0, long long s2 = 0) {
+  return ((uintptr_t)p & 15) == 0 && ld >= 4 && ld % 4 == 0 && s1 % 4 == 0 && s2 % 4 == 0;
+}
+
+}  // namespace
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
                                                        const float* __restrict__ W, int ldw,
                                                        int M, int N, int K, GemmEpi e) {
@@ -26,47 +135,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   const int tiles_m = (M + FBM - 1) / FBM;
   const int tn = blockIdx.x / tiles_m, tm = blockIdx.x - tn * tiles_m;
   const int m0 = tm * FBM, n0 = tn * FBN;
-
-  // staging: thread -> (row = tid/4, kq = tid%4): 4 lanes read one row's 64 contiguous bytes
-  const int srow = tid >> 2, kq = tid & 3;
-  const bool va = (m0 + srow) < M, vw = (n0 + srow) < N;
-  const float* gA = A + (size_t)(va ? m0 + srow : 0) * lda + kq * 4;
-  const float* gW = W + (size_t)(vw ? n0 + srow : 0) * ldw + kq * 4;
-  float4 ra, rw;
-  auto gload = [&](int k0) {
-    const bool kin = (k0 + kq * 4) < K;   // K % 4 == 0
-    ra = (va && kin) ? *reinterpret_cast<const float4*>(gA + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    rw = (vw && kin) ? *reinterpret_cast<const float4*>(gW + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-  };
-  auto lwrite = [&](int st) {
-    float* a = &sA[st][(kq * 4) * FLD + srow];
-    a[0] = ra.x; a[FLD] = ra.y; a[2 * FLD] = ra.z; a[3 * FLD] = ra.w;
-    float* w = &sW[st][(kq * 4) * FLD + srow];
-    w[0] = rw.x; w[FLD] = rw.y; w[2 * FLD] = rw.z; w[3 * FLD] = rw.w;
-  };
-
+  TileLoad<false, VEC> la, lw;
+  la.init(A, lda, M, K, m0, tid);
+  lw.init(W, ldw, N, K, n0, tid);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int nk = (K + FBK - 1) / FBK;
-  gload(0);
-  lwrite(0);
-  __syncthreads();
-  const int lr = lane & 31, lh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload((kt + 1) * FBK);
-    const float* a = &sA[kt & 1][wm * 32 + lr];
-    const float* w = &sW[kt & 1][wn * 32 + lr];
-#pragma unroll
-    for (int s = 0; s < FBK / 2; ++s) {
-      const float av = a[(2 * s + lh) * FLD];
-      const float wv = w[(2 * s + lh) * FLD];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc, 0, 0, 0);
-    }
-    if (kt + 1 < nk) lwrite((kt + 1) & 1);
-    __syncthreads();
-  }
+  f32_mainloop(la, lw, 0, (K + FBK - 1) / FBK, sA, sW, acc);
 
+  const int lr = lane & 31, lh = lane >> 5;
   const int m = m0 + wm * 32 + lr;
   if (m >= M) return;
   size_t orow = (size_t)m;
@@ -99,9 +176,85 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K,
                     const GemmEpi& e, hipStream_t s) {
   if (M <= 0 || N <= 0 || K <= 0) return 1;
-  if (K % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
   const int tiles = ((M + FBM - 1) / FBM) * ((N + FBN - 1) / FBN);
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e);
+  if (vec_ok(A, lda) && vec_ok(W, ldw)) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tiles), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e);
+  else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(tiles), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// ------------------------------------------------------------------------------------------------ batched / transposed-operand form
+template <bool AKM, bool WKM, bool VEC>
+__global__ __launch_bounds__(256) void gemm_f32x_kernel(GemmF32X g) {
+  __shared__ float sA[2][FBK * FLD];
+  __shared__ float sW[2][FBK * FLD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_m = (g.M + FBM - 1) / FBM;
+  const int tn = blockIdx.x / tiles_m, tm = blockIdx.x - tn * tiles_m;
+  const int m0 = tm * FBM, n0 = tn * FBN;
+  const int zb = blockIdx.y / g.hb, zh = blockIdx.y - zb * g.hb;
+  const int nkt = (g.K + FBK - 1) / FBK;
+  int kt0 = 0, kt1 = nkt;
+  if (g.ksplit > 1) {
+    const int per = (nkt + g.ksplit - 1) / g.ksplit;
+    kt0 = blockIdx.z * per; kt1 = kt0 + per < nkt ? kt0 + per : nkt;
+    if (kt0 >= kt1) return;                                   // uniform: before any barrier
+  }
+  const int kend = kt1 * FBK < g.K ? kt1 * FBK : g.K;
+  TileLoad<AKM, VEC> la;
+  TileLoad<WKM, VEC> lw;
+  la.init(g.A + zb * g.a_sb + zh * g.a_sh, g.lda, g.M, kend, m0, tid);
+  lw.init(g.W + zb * g.w_sb + zh * g.w_sh, g.ldw, g.N, kend, n0, tid);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  f32_mainloop(la, lw, kt0, kt1, sA, sW, acc);
+
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m = m0 + wm * 32 + lr;
+  if (m >= g.M) return;
+  float* crow = g.C + zb * g.c_sb + zh * g.c_sh + (size_t)m * g.ldc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = n0 + wn * 32 + 8 * q + 4 * lh + t;
+      if (n >= g.N) continue;
+      float v = acc[4 * q + t] * g.alpha;
+      if (g.ksplit > 1) {
+        if (g.bias && blockIdx.z == 0) v += g.bias[n];
+        unsafeAtomicAdd(crow + n, v);
+      } else {
+        if (g.bias) v += g.bias[n];
+        if (g.act == ACT_GELU) v = gelu_erf(v);
+        else if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (g.act == ACT_SIGMOID) v = sigmoidf_(v);
+        crow[n] = g.accumulate ? crow[n] + v : v;
+      }
+    }
+  }
+}
+
+int launch_gemm_f32x(const GemmF32X& g_, hipStream_t s) {
+  GemmF32X g = g_;
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.W || !g.C) return 1;
+  if (g.batch < 1) g.batch = 1;
+  if (g.hb < 1) g.hb = 1;
+  if (g.batch % g.hb || g.batch > 65535) return 2;
+  if (g.ksplit < 1) g.ksplit = 1;
+  if (g.ksplit > 1 && g.act != ACT_NONE) return 2;
+  const int nkt = (g.K + FBK - 1) / FBK;
+  if (g.ksplit > nkt) g.ksplit = nkt;
+  const int tiles = ((g.M + FBM - 1) / FBM) * ((g.N + FBN - 1) / FBN);
+  const bool vec = vec_ok(g.A, g.lda, g.a_sb, g.a_sh) && vec_ok(g.W, g.ldw, g.w_sb, g.w_sh);
+  const dim3 grid(tiles, g.batch, g.ksplit);
+#define F32X_LAUNCH(AK, WK) do { if (vec) hipLaunchKernelGGL((gemm_f32x_kernel<AK, WK, true>), grid, dim3(256), 0, s, g); \
+                                 else hipLaunchKernelGGL((gemm_f32x_kernel<AK, WK, false>), grid, dim3(256), 0, s, g); } while (0)
+  if (g.a_kmajor && g.w_kmajor) F32X_LAUNCH(true, true);
+  else if (g.a_kmajor) F32X_LAUNCH(true, false);
+  else if (g.w_kmajor) F32X_LAUNCH(false, true);
+  else F32X_LAUNCH(false, false);
+#undef F32X_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -155,6 +155,14 @@ enum dod_act { DOD_ACT_NONE = 0, DOD_ACT_RELU = 1, DOD_ACT_GELU = 2, DOD_ACT_SIG
 int dod_op_linear(int in_dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                   const float* bias, const float* scale, const float* resid, int ldr,
                   void* out, int out_dtype, int ldc, int act, void* stream);
+/* The fp32 product in the forms the native training step uses (train.py:1079-1109):
+ *   C[z] (+)= alpha * A[z] W[z]^T,  z = zb * hb + zh over `batch` strided views (X[z] = X + zb * x_sb + zh * x_sh, in floats);
+ * a_kmajor / w_kmajor: that operand is stored [K, rows] (the transposed products of a backward, no transposed copies);
+ * ksplit > 1 splits K over the grid and accumulates atomically (C must already hold the addend). */
+int dod_op_gemm_f32x(const float* A, int lda, int a_kmajor, long long a_sb, long long a_sh,
+                     const float* W, int ldw, int w_kmajor, long long w_sb, long long w_sh,
+                     float* C, int ldc, long long c_sb, long long c_sh,
+                     int M, int N, int K, int batch, int hb, float alpha, int accumulate, int ksplit, void* stream);
 /* fp8 (OCP e4m3) operands, one byte per element: out = act((Aq Wq^T) * a_scale[m] * w_scale[n] + bias) * scale + resid.
  * K % 64 == 0, lda / ldw in bytes, % 16 == 0.  The ViT-g fp8 configuration's linears (BASELINE configs[4]). */
 int dod_op_linear_fp8(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale,

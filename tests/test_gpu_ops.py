@@ -105,8 +105,10 @@ def test_linear_rejects_bad_shapes(G):
     W = torch.zeros(8, 100, device=G.dev(), dtype=torch.bfloat16)
     with pytest.raises(ValueError):
         G.op_linear(A, W)            # K % 64 != 0 for the bf16 kernel
-    with pytest.raises(ValueError):
-        G.op_linear(torch.zeros(8, 6, device=G.dev()), torch.zeros(8, 6, device=G.dev()))   # K % 4
+    # the fp32 kernel takes any K and pitch (scalar loads when a pitch rules out float4)
+    A, W = _n("odd.A", (9, 6)), _n("odd.W", (5, 6))
+    out = G.op_linear(G.to_gpu(A), G.to_gpu(W))
+    assert rel_err(out.cpu().numpy(), A.astype(np.float64) @ W.astype(np.float64).T) < 3e-6
 
 
 def _attn_ref(q, k, v, scale):
@@ -213,3 +215,56 @@ def test_im2col_is_exact(G, B, H, W):
     x = torch.from_numpy(img)[:, :, :gh * p, :gw * p].reshape(B, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, K)
     got = out.cpu()
     assert torch.equal(got[:, :K], x) and float(got[:, K:].abs().max()) == 0.0
+
+
+def _gemm_f32x(A, lda, akm, asb, ash, W, ldw, wkm, wsb, wsh, Cm, ldc, csb, csh, M, N, K, batch, hb, alpha, acc, ksplit):
+    nat.check(nat.lib().dod_op_gemm_f32x(nat.ptr(A), lda, akm, asb, ash, nat.ptr(W), ldw, wkm, wsb, wsh, nat.ptr(Cm), ldc, csb, csh,
+                                         M, N, K, batch, hb, alpha, acc, ksplit, nat.stream_ptr()))
+
+
+@pytest.mark.parametrize("akm,wkm", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (100, 50, 768), (257, 64, 257), (333, 95, 130), (1600, 768, 1024), (768, 2, 4112)])
+def test_gemm_f32x_operand_layouts(G, M, N, K, akm, wkm):
+    """The training step's product forms (train.py:1079-1109): either operand k-major (stored [K, rows]), odd sizes and pitches
+    that rule out vector loads, alpha, accumulate, and the row split with atomic accumulate -- against the fp64 product."""
+    A, W, C0 = _n("x.A", (M, K)), _n("x.W", (N, K), 0.05), _n("x.C", (M, N))
+    ref = torch.from_numpy(A).double() @ torch.from_numpy(W).double().t()
+    Ad = G.to_gpu(np.ascontiguousarray(A.T) if akm else A)
+    Wd = G.to_gpu(np.ascontiguousarray(W.T) if wkm else W)
+    lda, ldw = (M if akm else K), (N if wkm else K)
+    out = torch.empty(M, N, device=G.dev())
+    _gemm_f32x(Ad, lda, akm, 0, 0, Wd, ldw, wkm, 0, 0, out, N, 0, 0, M, N, K, 1, 1, 1.0, 0, 1)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 3e-6
+    want = torch.from_numpy(C0).double() + 0.5 * ref
+    out = G.to_gpu(C0)
+    _gemm_f32x(Ad, lda, akm, 0, 0, Wd, ldw, wkm, 0, 0, out, N, 0, 0, M, N, K, 1, 1, 0.5, 1, 1)
+    assert rel_err(out.cpu().numpy(), want.numpy()) < 3e-6
+    for ks in (2, 7):
+        out = G.to_gpu(C0)
+        _gemm_f32x(Ad, lda, akm, 0, 0, Wd, ldw, wkm, 0, 0, out, N, 0, 0, M, N, K, 1, 1, 0.5, 1, ks)
+        assert rel_err(out.cpu().numpy(), want.numpy()) < 3e-6, ks
+
+
+@pytest.mark.parametrize("B,H,Q,dh", [(2, 4, 7, 16), (3, 8, 100, 96), (2, 12, 257, 64)])
+def test_gemm_f32x_batched_attention_views(G, B, H, Q, dh):
+    """The (image, head) batch over strided views of a [B*Q, 3*D] q|k|v buffer, as the self-attention forward and adjoint issue it:
+    S = scale q k^T into a [B*H, Q, Qp] scratch, O = P v with v as the k-major operand, dk = dS^T q with both operands k-major."""
+    D = H * dh
+    qkv = _n("xb.qkv", (B * Q, 3 * D))
+    Qp = (Q + 3) // 4 * 4
+    t = torch.from_numpy(qkv).double().view(B, Q, 3, H, dh)
+    q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))        # [B, H, Q, dh]
+    S_ref = 0.25 * q @ k.transpose(-1, -2)
+    qd = G.to_gpu(qkv)
+    S = torch.zeros(B * H, Q, Qp, device=G.dev())
+    ld, qs, ss = 3 * D, Q * 3 * D, Q * Qp
+    _gemm_f32x(qd, ld, 0, qs, dh, qd[:, D:], ld, 0, qs, dh, S, Qp, ss * H, ss, Q, Q, dh, B * H, H, 0.25, 0, 1)
+    assert rel_err(S[:, :, :Q].cpu().numpy().reshape(B, H, Q, Q), S_ref.numpy()) < 3e-6
+    O = torch.empty(B * Q, D, device=G.dev())
+    _gemm_f32x(S, Qp, 0, ss * H, ss, qd[:, 2 * D:], ld, 1, qs, dh, O, D, Q * D, dh, Q, dh, Q, B * H, H, 1.0, 0, 1)
+    O_ref = (S_ref @ v).permute(0, 2, 1, 3).reshape(B * Q, D)
+    assert rel_err(O.cpu().numpy(), O_ref.numpy()) < 3e-6
+    dK = torch.empty(B * Q, D, device=G.dev())
+    _gemm_f32x(S, Qp, 1, ss * H, ss, qd, ld, 1, qs, dh, dK, D, Q * D, dh, Q, dh, Q, B * H, H, 1.0, 0, 1)
+    dK_ref = (S_ref.transpose(-1, -2) @ q).permute(0, 2, 1, 3).reshape(B * Q, D)
+    assert rel_err(dK.cpu().numpy(), dK_ref.numpy()) < 3e-6
