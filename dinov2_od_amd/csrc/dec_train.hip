@@ -19,6 +19,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -470,7 +471,8 @@ int gemm_tn_acc(const float* Y, int ldy, const float* X, int ldx, int M, int R, 
   GemmF32X g = xgemm(Y, ldy, true, X, ldx, true, C, ldc, R, Cc, M, alpha, true);
   const int tiles = ((R + 63) / 64) * ((Cc + 63) / 64), nkt = (M + 15) / 16;
   int ks = 1;
-  if (tiles < 512) { ks = (768 + tiles - 1) / tiles; const int cap = nkt / 8 > 1 ? nkt / 8 : 1; if (ks > cap) ks = cap; }
+  static const int target = [] { const char* e = getenv("DINODET_F32_KSPLIT_WGS"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
+  if (tiles < target) { ks = (target + tiles - 1) / tiles; const int cap = nkt / 8 > 1 ? nkt / 8 : 1; if (ks > cap) ks = cap; }
   g.ksplit = ks;
   return launch_gemm_f32x(g, s);
 }

@@ -9,9 +9,11 @@
 // (D = W_tile * A_tile^T) so a lane owns an output row and register quads run along n.
 // LDS holds both operands k-major ([k][row], stride 66 floats) so the one-float-per-lane MFMA operands
 // are conflict-free ds_read_b32 (lanes 0-31 consecutive rows at k, lanes 32-63 at k+1).
-// Global loads run a four-deep register ring ahead of the LDS stage: most of these launches put one or two workgroups on a CU,
-// where a single k-tile in flight left every iteration waiting out a full memory latency (1 600-row decoder linears: 47 us for
-// 1.9 GFLOP before the ring).
+// Global loads run a four-deep register ring ahead of the LDS stage.  Measured on the training step's products (ViT-B 224x224,
+// batch 16): 4 112 x 3 072 x 768 (3 120 workgroups) 91 TFLOP/s = 58 % of the fp32 MFMA peak; one workgroup per CU (1 600 x 768 x
+// 768, 300 workgroups) 40 TFLOP/s with or without the ring, and slower (51 vs 48 us; the large grids 255 vs 212 us) with four
+// k-tiles per LDS stage and barrier -- a lone workgroup's k-tile takes ~1 us whatever is in flight behind it, co-resident
+// workgroups are what overlap it.
 #include "dod_common.h"
 #include <cstdlib>
 #include <cstring>
@@ -128,8 +130,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
                                                        const float* __restrict__ W, int ldw,
                                                        int M, int N, int K, GemmEpi e) {
-  __shared__ float sA[2][FBK * FLD];
-  __shared__ float sW[2][FBK * FLD];
+  __shared__ __attribute__((aligned(16))) float f32_smem[4 * FBK * FLD];     // sA[2] | sW[2]; the split-K epilogue's [64][65] tile
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_m = (M + FBM - 1) / FBM;
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  f32_mainloop(la, lw, 0, (K + FBK - 1) / FBK, sA, sW, acc);
+  f32_mainloop(la, lw, 0, (K + FBK - 1) / FBK, reinterpret_cast<float (*)[FBK * FLD]>(f32_smem),
+               reinterpret_cast<float (*)[FBK * FLD]>(f32_smem + 2 * FBK * FLD), acc);
 
   const int lr = lane & 31, lh = lane >> 5;
   const int m = m0 + wm * 32 + lr;
@@ -186,8 +188,7 @@ int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int
 // ------------------------------------------------------------------------------------------------ batched / transposed-operand form
 template <bool AKM, bool WKM, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32x_kernel(GemmF32X g) {
-  __shared__ float sA[2][FBK * FLD];
-  __shared__ float sW[2][FBK * FLD];
+  __shared__ __attribute__((aligned(16))) float f32_smem[4 * FBK * FLD];     // sA[2] | sW[2]; the split-K epilogue's [64][65] tile
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_m = (g.M + FBM - 1) / FBM;
@@ -209,12 +210,32 @@ __global__ __launch_bounds__(256) void gemm_f32x_kernel(GemmF32X g) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  f32_mainloop(la, lw, kt0, kt1, sA, sW, acc);
+  f32_mainloop(la, lw, kt0, kt1, reinterpret_cast<float (*)[FBK * FLD]>(f32_smem),
+               reinterpret_cast<float (*)[FBK * FLD]>(f32_smem + 2 * FBK * FLD), acc);
 
   const int lr = lane & 31, lh = lane >> 5;
+  float* cz = g.C + zb * g.c_sb + zh * g.c_sh;
+  if (g.ksplit > 1) {
+    // atomic accumulate of the slice's partial tile, staged through LDS so that one wave instruction covers 64 consecutive
+    // columns of one row (a lane-owns-a-row scatter of 4-byte atomics ran at ~40 per ns: 80 us for a 384 x 768 gradient)
+    __syncthreads();                                   // every wave is done reading the last stage
+    float* T = f32_smem;                               // [64][65]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) T[(wm * 32 + lr) * 65 + wn * 32 + 8 * q + 4 * lh + t] = acc[4 * q + t] * g.alpha;
+    __syncthreads();
+    const int n = n0 + lane;
+    const float bv = (g.bias && blockIdx.z == 0 && n < g.N) ? g.bias[n] : 0.f;
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = wid * 16 + rr, m = m0 + row;
+      if (m < g.M && n < g.N) unsafeAtomicAdd(cz + (size_t)m * g.ldc + n, T[row * 65 + lane] + bv);
+    }
+    return;
+  }
   const int m = m0 + wm * 32 + lr;
   if (m >= g.M) return;
-  float* crow = g.C + zb * g.c_sb + zh * g.c_sh + (size_t)m * g.ldc;
+  float* crow = cz + (size_t)m * g.ldc;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -222,16 +243,11 @@ __global__ __launch_bounds__(256) void gemm_f32x_kernel(GemmF32X g) {
       const int n = n0 + wn * 32 + 8 * q + 4 * lh + t;
       if (n >= g.N) continue;
       float v = acc[4 * q + t] * g.alpha;
-      if (g.ksplit > 1) {
-        if (g.bias && blockIdx.z == 0) v += g.bias[n];
-        unsafeAtomicAdd(crow + n, v);
-      } else {
-        if (g.bias) v += g.bias[n];
-        if (g.act == ACT_GELU) v = gelu_erf(v);
-        else if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
-        else if (g.act == ACT_SIGMOID) v = sigmoidf_(v);
-        crow[n] = g.accumulate ? crow[n] + v : v;
-      }
+      if (g.bias) v += g.bias[n];
+      if (g.act == ACT_GELU) v = gelu_erf(v);
+      else if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+      else if (g.act == ACT_SIGMOID) v = sigmoidf_(v);
+      crow[n] = g.accumulate ? crow[n] + v : v;
     }
   }
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""train()-mode step (forward + backward) on the drop-in detector: native frozen prefix + autograd composite ("hybrid")
-vs the all-composite evaluation (selected by an input that requires grad).  ViT-B/14 224x224, batch 16."""
+"""train()-mode step (forward + backward) on the drop-in detector, ViT-B/14 224x224, batch 16: the native step (HIP forward with a
+tape + HIP backward; the default) or, with DINODET_NATIVE_TRAIN=0, the native frozen prefix + the PyTorch autograd composite --
+against the all-composite evaluation (selected by an input that requires grad)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +13,8 @@ def step(inp):
     m.zero_grad(set_to_none=True)
     o = m(inp)
     (o["pred_logits"].square().mean() + o["pred_boxes"].mean()).backward()
-for name, mk in (("hybrid (native prefix)", lambda: x), ("all-composite", lambda: x.clone().requires_grad_(True))):
+first = "native prefix + composite" if os.environ.get("DINODET_NATIVE_TRAIN", "1") == "0" else "native step"
+for name, mk in ((first, lambda: x), ("all-composite", lambda: x.clone().requires_grad_(True))):
     for _ in range(2): step(mk())
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(5): step(mk())
