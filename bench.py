@@ -26,7 +26,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
   parity_gated_mode : the same workload in the DEFAULT precision of the drop-in modules, bf16x3 (split products on the bf16
                  MFMA cores, within the 1e-3 gate), with its own value / roofline / gpu_vs_oracle -- measured exactly like the
                  headline (N = 1 only);
-  also         : BASELINE configs[1] (ViT-B/14 224x224, batch 32) in both modes (N = 1 only).
+  also         : BASELINE configs[1] (ViT-B/14 224x224, batch 32) in both modes, and `train_step`: the native train()-mode step
+                 (section 8 row f1) against the autograd composite on the same frozen prefix (N = 1 only).
 Other workloads / modes: --workload {vits224,vitb224,vitl518,vitg518}, --precision {bf16,bf16x3,fp16x2,fp32,fp8}.
 `--rehearse-cpu` swaps the model for a stub on the CPU with gloo: it exercises launcher, sharding, barriers, timing and the
 overlapped gather without a GPU (tests/test_dist_cpu.py) and labels its line as a rehearsal -- never a measurement.
@@ -89,6 +90,41 @@ def build(name, queries, precision, device):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     del sd
     return m.to(device).eval(), bb, dc
+
+
+def train_step_ms(device, steps=10, warmup=3):
+    """SURVEY section 8 row f1 beside the forward numbers: one train()-mode step (forward + backward of the trainable subset:
+    decoder, heads, LoRA A/B of the last two blocks; train.py:1079-1109) on ViT-B/14 224x224, batch 16 -- the native HIP step and,
+    for comparison, the PyTorch autograd composite on the same native frozen prefix (DINODET_NATIVE_TRAIN=0)."""
+    import torch
+    m, _, _ = build("facebook/dinov2-base", 100, "bf16", device)
+    m.train()
+    x = torch.rand(16, 3, 224, 224, device=device)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        o = m(x)
+        (o["pred_logits"].square().mean() + o["pred_boxes"].mean()).backward()
+
+    out = {"workload": "ViT-B/14 224x224, 100 queries, batch 16, forward + backward (dropout 0.1), fp32 trainable path"}
+    prev = os.environ.get("DINODET_NATIVE_TRAIN")
+    try:
+        for key, env in (("native_ms", "1"), ("composite_on_native_prefix_ms", "0")):
+            os.environ["DINODET_NATIVE_TRAIN"] = env
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            out[key] = round((time.perf_counter() - t) / steps * 1e3, 3)
+    finally:
+        if prev is None:
+            os.environ.pop("DINODET_NATIVE_TRAIN", None)
+        else:
+            os.environ["DINODET_NATIVE_TRAIN"] = prev
+    return out
 
 
 def host_cores():
@@ -471,6 +507,12 @@ def worker(a):
                         res["also"][f"vitb224_{prec}"] = r2
                     except Exception as e:
                         res["also"][f"vitb224_{prec}"] = {"error": f"{type(e).__name__}: {e}"}
+                try:
+                    del x2
+                    torch.cuda.empty_cache()
+                    res["also"]["train_step"] = train_step_ms(device)
+                except Exception as e:
+                    res["also"]["train_step"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -451,28 +451,41 @@ GemmEpi gepi(const float* bias, float* out, int ldc, int act = ACT_NONE, const f
   e.bias = bias; e.out_f32 = out; e.ldc = ldc; e.act = act; e.resid = resid; e.ldr = ldr;
   return e;
 }
-// Y[M,N] = act(X[M,K] W[N,K]^T + b)
-int lin_fwd(const float* X, int ldx, const float* W, const float* b, int M, int N, int K, float* Y, int ldy, int act, hipStream_t s) {
-  return launch_gemm_f32(X, ldx, W, K, M, N, K, gepi(b, Y, ldy, act), s);
-}
 GemmF32X xgemm(const float* A, int lda, bool a_km, const float* W, int ldw, bool w_km, float* C, int ldc, int M, int N, int K, float alpha, bool accumulate) {
   GemmF32X g; memset(&g, 0, sizeof g);
   g.A = A; g.lda = lda; g.a_kmajor = a_km; g.W = W; g.ldw = ldw; g.w_kmajor = w_km; g.C = C; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K; g.batch = 1; g.hb = 1; g.alpha = alpha; g.accumulate = accumulate; g.ksplit = 1;
   return g;
 }
+// K slices for a product whose 64x64 tiles leave most of the chip idle (the decoder's 1 600-row linears: 300 tiles, a lone
+// workgroup's 16-k tile takes ~1 us): target ~768 workgroups of at least 8 k-tiles each; 1 = do not split
+int ksplit_for(int rows, int cols, int K) {
+  static const int target = [] { const char* e = getenv("DINODET_F32_KSPLIT_WGS"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
+  const int tiles = ((rows + 63) / 64) * ((cols + 63) / 64), nkt = (K + 15) / 16;
+  if (tiles >= target) return 1;
+  int ks = (target + tiles - 1) / tiles;
+  const int cap = nkt / 8 > 1 ? nkt / 8 : 1;
+  return ks > cap ? cap : ks;
+}
+// Y[M,N] = act(X[M,K] W[N,K]^T + b).  Never K-split: the forward stays a bit-reproducible function of (inputs, seed).
+int lin_fwd(const float* X, int ldx, const float* W, const float* b, int M, int N, int K, float* Y, int ldy, int act, hipStream_t s) {
+  return launch_gemm_f32(X, ldx, W, K, M, N, K, gepi(b, Y, ldy, act), s);
+}
 // dX[M,K] (+)= dY[M,N] W[N,K]: W [N, K] is the k-major operand of the product over n
 int lin_bwd_x(const float* dY, int ldy, const float* W, int M, int N, int K, float* dX, bool accumulate, hipStream_t s) {
-  return launch_gemm_f32x(xgemm(dY, ldy, false, W, K, true, dX, K, M, K, N, 1.0f, accumulate), s);
+  GemmF32X g = xgemm(dY, ldy, false, W, K, true, dX, K, M, K, N, 1.0f, accumulate);
+  g.ksplit = ksplit_for(M, K, N);
+  if (g.ksplit > 1 && !accumulate) {
+    if (hipMemsetAsync(dX, 0, (size_t)M * K * 4, s) != hipSuccess) return 3;
+    g.accumulate = 1;
+  }
+  return launch_gemm_f32x(g, s);
 }
 // C[R,Cc] += alpha * Y[M,R]^T X[M,Cc]: both operands k-major over the M rows.  A small output (weight gradients: a few dozen to
 // a few hundred tiles against a reduction over thousands of rows) splits the rows over grid.z and accumulates atomically.
 int gemm_tn_acc(const float* Y, int ldy, const float* X, int ldx, int M, int R, int Cc, float* C, int ldc, float alpha, hipStream_t s) {
   GemmF32X g = xgemm(Y, ldy, true, X, ldx, true, C, ldc, R, Cc, M, alpha, true);
-  const int tiles = ((R + 63) / 64) * ((Cc + 63) / 64), nkt = (M + 15) / 16;
-  int ks = 1;
-  static const int target = [] { const char* e = getenv("DINODET_F32_KSPLIT_WGS"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
-  if (tiles < target) { ks = (target + tiles - 1) / tiles; const int cap = nkt / 8 > 1 ? nkt / 8 : 1; if (ks > cap) ks = cap; }
+  const int ks = ksplit_for(R, Cc, M);
   g.ksplit = ks;
   return launch_gemm_f32x(g, s);
 }
