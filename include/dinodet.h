@@ -158,7 +158,9 @@ int dod_op_linear(int in_dtype, const void* A, int lda, const void* W, int ldw, 
 /* The fp32 product in the forms the native training step uses (train.py:1079-1109):
  *   C[z] (+)= alpha * A[z] W[z]^T,  z = zb * hb + zh over `batch` strided views (X[z] = X + zb * x_sb + zh * x_sh, in floats);
  * a_kmajor / w_kmajor: that operand is stored [K, rows] (the transposed products of a backward, no transposed copies);
- * ksplit > 1 splits K over the grid and accumulates atomically (C must already hold the addend). */
+ * ksplit > 1 splits K over the grid and accumulates atomically (C must already hold the addend).
+ * Operands whose pointer, pitch and batch strides are multiples of 4 floats are read as float4: such a buffer must hold whole
+ * pitches (rows * ld floats), as any [rows, ld] allocation does. */
 int dod_op_gemm_f32x(const float* A, int lda, int a_kmajor, long long a_sb, long long a_sh,
                      const float* W, int ldw, int w_kmajor, long long w_sb, long long w_sh,
                      float* C, int ldc, long long c_sb, long long c_sh,

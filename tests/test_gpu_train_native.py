@@ -174,16 +174,20 @@ def test_detector_train_step_uses_the_native_decoder_backward():
         assert rel_err(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-3, k      # LoRA grads pass through two blocks of fp32 autograd
 
 
-@pytest.mark.parametrize("variant,R,B", [("micro", 70, 3), ("small", 224, 2), ("base", 224, 2)])
+@pytest.mark.parametrize("variant,R,B", [("micro", 70, 3), ("micro_r12", 70, 3), ("small", 224, 2), ("base", 224, 2), ("small", 518, 1)])
 def test_native_backbone_tail_backward_matches_composite_autograd(variant, R, B):
     """The LoRA-adapted blocks + final LayerNorm + projection (dod_backbone_tail_train_*): memory and the gradients of every
-    lora_A / lora_B and of the projection against the composite's autograd on the same frozen-prefix output."""
+    lora_A / lora_B and of the projection against the composite's autograd on the same frozen-prefix output.  micro_r12: rank 12
+    takes the generic rank-r products (k-major fp32 GEMMs) instead of the r <= 8 kernels; 518: 1 370 tokens per image."""
     from dinov2_od_amd.config import BackboneConfig
     from dinov2_od_amd.models import DINOv2Backbone
     from tests import gpu_util as G
-    if variant == "micro":
+    if variant.startswith("micro"):
         bb = cases.micro_bb(False)
         bb.target_dim, bb.layers = 64, 3          # one frozen block in front of the two adapted ones (the native prefix needs >= 1)
+        if variant == "micro_r12":
+            bb.lora_r = 12
+        variant = "micro"
     else:
         bb = BackboneConfig.from_name(f"facebook/dinov2-{variant}", lora_r=2, lora_alpha=1.0, target_dim=256)
     m = DINOv2Backbone(variant, lora_r=bb.lora_r, lora_alpha=bb.lora_alpha, target_dim=bb.target_dim, pretrained=False, precision="fp32", config=bb)
