@@ -61,7 +61,7 @@ def backbone_forward(m, pixel_values):
         if os.environ.get("DINODET_NATIVE_TRAIN", "1") != "0" and _native_train.tail_supported(m, layers, h):
             return _native_train.backbone_tail(m, h, layers)
     else:
-        x = emb.patch_embeddings.projection(pixel_values.float()).flatten(2).transpose(1, 2)      # :141-149
+        x = emb.patch_embeddings.projection(pixel_values.to(emb.patch_embeddings.projection.weight.dtype)).flatten(2).transpose(1, 2)      # :141-149
         h = torch.cat((emb.cls_token.expand(B, -1, -1), x), dim=1) + _pos_embed(emb.position_embeddings, bb.patch, H, W)
     nh = bb.heads
     for L in layers:                                                                         # :361-380

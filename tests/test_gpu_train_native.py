@@ -210,10 +210,30 @@ def test_native_backbone_tail_backward_matches_composite_autograd(variant, R, B)
     m1, g1 = run(True)
     assert rel_err(m1.cpu().numpy(), m0.cpu().numpy()) < 2e-5
     assert set(g0) == set(g1) and sum("lora_A" in k for k in g1) == 12 and "projection.weight" in g1
+    # the same step in float64 on the CPU (the composite, every block): which of the two fp32 evaluations is closer to it
+    m64 = DINOv2Backbone(variant, lora_r=bb.lora_r, lora_alpha=bb.lora_alpha, target_dim=bb.target_dim, pretrained=False, precision="fp32", config=bb)
+    m64.load_state_dict({k: torch.from_numpy(v) for k, v in synth.backbone_state_dict(bb, seed=1, prefix="").items()}, strict=True)
+    m64 = m64.double().train()
+    os.environ["DINODET_COMPOSITE_ON_CPU"] = "1"
+    try:
+        (m64(x.cpu().double()) * wgt.cpu().double()).sum().backward()
+    finally:
+        os.environ.pop("DINODET_COMPOSITE_ON_CPU", None)
+    g64 = {k: p.grad for k, p in m64.named_parameters() if p.grad is not None}
+    assert set(g64) == set(g1)
+    # rounding grows with the length of the softmax / token reductions: 257 tokens stay inside 1e-4 of the fp32 composite; at 1 370
+    # tokens the two fp32 evaluations sit ~1e-4 apart and the native one must be no further from float64 than twice the composite
+    tol = 1e-4 if N <= 257 else 3e-4
     worst = ("", 0.0)
+    worst64 = ("", 0.0, 0.0)
     for k in g0:
         e = rel_err(g1[k].cpu().numpy(), g0[k].cpu().numpy())
         worst = max(worst, (k, e), key=lambda t: t[1])
-        assert e < 1e-4, (k, e)
+        assert e < tol, (k, e)
+        ref = g64[k].numpy()
+        en, ec = rel_err(g1[k].double().cpu().numpy(), ref), rel_err(g0[k].double().cpu().numpy(), ref)
+        worst64 = max(worst64, (k, en, ec), key=lambda t: t[1])
+        assert en < max(2e-5, 2.0 * ec), (k, en, ec)
     assert worst[1] > 0.0, "both runs took the same path"
+    print(f"backbone tail {variant} R={R}: vs float64 worst native {worst64[1]:.2e} (composite {worst64[2]:.2e}) at {worst64[0]}")
     print(f"backbone tail {variant} R={R}: memory {rel_err(m1.cpu().numpy(), m0.cpu().numpy()):.2e}, worst gradient {worst[0]} {worst[1]:.2e}")
