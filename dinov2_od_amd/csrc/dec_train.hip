@@ -181,7 +181,7 @@ int ln_bwd(const float* x, const float* gamma, const float* dy, float eps, int r
 // ------------------------------------------------------------------------------------------------ multi-head self-attention (Q x Q)
 // nn.MultiheadAttention (deformable_attention.py:195, 233): softmax((q k^T) / sqrt(dh)), dropout on the probabilities, times v.
 // qkv [B*Q, 3*Dd] = [q | k | v], head h at columns h*dh.  Scores, probabilities and their adjoints are [B*Hd, Q, Qp] fp32 scratch
-// (Qp = Q rounded up to 4); every product is one batched fp32-MFMA GEMM over (image, head) on strided views of qkv / dO / dqkv:
+// (Qp = Q rounded up to 4); every product is one batched fp32-MFMA GEMM over (image, head) on strided views of qkv / dO / dqkv, a chunk of images per pass:
 //   forward : S = scale q k^T  ->  row kernel: Pd = dropout(softmax(S))  ->  O = Pd v
 //   backward: S = scale q k^T, dP = dO v^T  ->  row kernel: Pd, dS = P (keep dP - sum_j keep dP P)
 //             ->  dq = scale dS k,  dk = scale dS^T q,  dv = Pd^T dO
@@ -192,11 +192,13 @@ int ln_bwd(const float* x, const float* gamma, const float* dy, float eps, int r
 #define MHA_RT (MHA_MAXQ / 64)
 
 // one wave per score row; item = (b*Hd + h)*Q + i is also the dropout counter base (mask element = item*Q + j)
-__global__ __launch_bounds__(256) void mha_softmax_fwd_kernel(float* __restrict__ S, int Q, int Qp, long nrows, float p, unsigned long long key) {
+__global__ __launch_bounds__(256) void mha_softmax_fwd_kernel(float* __restrict__ S, int Q, int Qp, long nrows, long item_base, float p,
+                                                              unsigned long long key) {
   const int lane = threadIdx.x & 63;
-  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= nrows) return;
-  float* row = S + (size_t)item * Qp;
+  const long local = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (local >= nrows) return;
+  const long item = item_base + local;            // rows of an image chunk; the dropout counter runs over the whole batch
+  float* row = S + (size_t)local * Qp;
   float v[MHA_RT];
   float mx = -INFINITY;
 #pragma unroll
@@ -218,13 +220,14 @@ __global__ __launch_bounds__(256) void mha_softmax_fwd_kernel(float* __restrict_
   }
 }
 // SP: scores in, dropped probabilities out;  DD: d(loss)/d(dropped probabilities) in, d(loss)/d(scores) out
-__global__ __launch_bounds__(256) void mha_softmax_bwd_kernel(float* __restrict__ SP, float* __restrict__ DD, int Q, int Qp, long nrows, float p,
-                                                              unsigned long long key) {
+__global__ __launch_bounds__(256) void mha_softmax_bwd_kernel(float* __restrict__ SP, float* __restrict__ DD, int Q, int Qp, long nrows, long item_base,
+                                                              float p, unsigned long long key) {
   const int lane = threadIdx.x & 63;
-  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= nrows) return;
-  float* srow = SP + (size_t)item * Qp;
-  float* drow = DD + (size_t)item * Qp;
+  const long local = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (local >= nrows) return;
+  const long item = item_base + local;
+  float* srow = SP + (size_t)local * Qp;
+  float* drow = DD + (size_t)local * Qp;
   float v[MHA_RT], g[MHA_RT];
   float mx = -INFINITY;
 #pragma unroll
@@ -264,38 +267,66 @@ GemmF32X mha_gemm(const float* A, int lda, long long a_sb, long long a_sh, bool 
   g.M = M; g.N = N; g.K = K; g.batch = B * Hd; g.hb = Hd; g.alpha = alpha; g.ksplit = 1;
   return g;
 }
-inline size_t mha_scratch_floats(int B, int Hd, int Q) { return (size_t)B * Hd * Q * up4((size_t)Q); }
+// Images per pass: the score / adjoint scratch ([images*Hd, Q, Qp] fp32, two of them in the backward) is capped at 1 GB per buffer
+// (DINODET_MHA_CHUNK_MB) instead of growing with the batch (1 370 tokens x 12 heads: 90 MB per image per buffer).  Passes small
+// enough to keep the scores in the 256 MB Infinity Cache between launches were measured and do not pay: ViT-B 518x518, batch 8,
+// one image per pass 23.0 ms per step, two 22.0, the whole batch in one pass 21.7.
+inline int mha_chunk_images(int B, int Hd, int Q) {
+  const size_t per = (size_t)Hd * Q * up4((size_t)Q) * 4;
+  static const size_t mb = [] { const char* e = getenv("DINODET_MHA_CHUNK_MB"); return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)1024; }();
+  size_t c = (mb << 20) / (per ? per : 1);
+  if (c < 1) c = 1;
+  return c > (size_t)B ? B : (int)c;
+}
+inline size_t mha_scratch_floats(int B, int Hd, int Q) { return (size_t)mha_chunk_images(B, Hd, Q) * Hd * Q * up4((size_t)Q); }
 
-// S: [B*Hd, Q, Qp] scratch
+// S: mha_scratch_floats() of scratch
 static int launch_mha_fwd_train(const float* qkv, int ld, float* out, int ldo, float* S, int B, int Q, int Hd, int Dd, int dh, float scale, float p,
                                 unsigned long long key, hipStream_t s) {
   const int Qp = (int)up4((size_t)Q);
   const long long qs = (long long)Q * ld, ss = (long long)Q * Qp;
-  int rc = launch_gemm_f32x(mha_gemm(qkv, ld, qs, dh, false, qkv + Dd, ld, qs, dh, false, S, Qp, ss * Hd, ss, Q, Q, dh, B, Hd, scale), s);
-  if (rc) return rc;
-  const long nrows = (long)B * Hd * Q;
-  hipLaunchKernelGGL(mha_softmax_fwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, S, Q, Qp, nrows, p, key);
-  if (hipGetLastError() != hipSuccess) return 3;
-  return launch_gemm_f32x(mha_gemm(S, Qp, ss * Hd, ss, false, qkv + 2 * Dd, ld, qs, dh, true, out, ldo, (long long)Q * ldo, dh, Q, dh, Q, B, Hd, 1.0f), s);
+  const int cb = mha_chunk_images(B, Hd, Q);
+  for (int b0 = 0; b0 < B; b0 += cb) {
+    const int nb = B - b0 < cb ? B - b0 : cb;
+    const float* q0 = qkv + (size_t)b0 * qs;
+    int rc = launch_gemm_f32x(mha_gemm(q0, ld, qs, dh, false, q0 + Dd, ld, qs, dh, false, S, Qp, ss * Hd, ss, Q, Q, dh, nb, Hd, scale), s);
+    if (rc) return rc;
+    const long nrows = (long)nb * Hd * Q;
+    hipLaunchKernelGGL(mha_softmax_fwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, S, Q, Qp, nrows, (long)b0 * Hd * Q, p, key);
+    if (hipGetLastError() != hipSuccess) return 3;
+    rc = launch_gemm_f32x(mha_gemm(S, Qp, ss * Hd, ss, false, q0 + 2 * Dd, ld, qs, dh, true, out + (size_t)b0 * Q * ldo, ldo, (long long)Q * ldo, dh, Q, dh, Q,
+                                   nb, Hd, 1.0f), s);
+    if (rc) return rc;
+  }
+  return 0;
 }
-// dS, Pd: [B*Hd, Q, Qp] scratch
+// dS, Pd: mha_scratch_floats() of scratch each
 static int launch_mha_bwd(const float* qkv, int ld, const float* dO, int ldo, float* dqkv, float* dS, float* Pd, int B, int Q, int Hd, int Dd,
                           int dh, float scale, float p, unsigned long long key, hipStream_t s) {
   const int Qp = (int)up4((size_t)Q);
   const long long qs = (long long)Q * ld, os = (long long)Q * ldo, ss = (long long)Q * Qp;
-  int rc = launch_gemm_f32x(mha_gemm(qkv, ld, qs, dh, false, qkv + Dd, ld, qs, dh, false, Pd, Qp, ss * Hd, ss, Q, Q, dh, B, Hd, scale), s);
-  if (rc) return rc;
-  rc = launch_gemm_f32x(mha_gemm(dO, ldo, os, dh, false, qkv + 2 * Dd, ld, qs, dh, false, dS, Qp, ss * Hd, ss, Q, Q, dh, B, Hd, 1.0f), s);
-  if (rc) return rc;
-  const long nrows = (long)B * Hd * Q;
-  hipLaunchKernelGGL(mha_softmax_bwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, Pd, dS, Q, Qp, nrows, p, key);
-  if (hipGetLastError() != hipSuccess) return 3;
-  // dq = scale dS k;  dk = scale dS^T q;  dv = Pd^T dO      (k, q, dO enter as the k-major operand: [token, dh] views)
-  rc = launch_gemm_f32x(mha_gemm(dS, Qp, ss * Hd, ss, false, qkv + Dd, ld, qs, dh, true, dqkv, ld, qs, dh, Q, dh, Q, B, Hd, scale), s);
-  if (rc) return rc;
-  rc = launch_gemm_f32x(mha_gemm(dS, Qp, ss * Hd, ss, true, qkv, ld, qs, dh, true, dqkv + Dd, ld, qs, dh, Q, dh, Q, B, Hd, scale), s);
-  if (rc) return rc;
-  return launch_gemm_f32x(mha_gemm(Pd, Qp, ss * Hd, ss, true, dO, ldo, os, dh, true, dqkv + 2 * Dd, ld, qs, dh, Q, dh, Q, B, Hd, 1.0f), s);
+  const int cb = mha_chunk_images(B, Hd, Q);
+  for (int b0 = 0; b0 < B; b0 += cb) {
+    const int nb = B - b0 < cb ? B - b0 : cb;
+    const float* q0 = qkv + (size_t)b0 * qs;
+    const float* o0 = dO + (size_t)b0 * os;
+    float* g0 = dqkv + (size_t)b0 * qs;
+    int rc = launch_gemm_f32x(mha_gemm(q0, ld, qs, dh, false, q0 + Dd, ld, qs, dh, false, Pd, Qp, ss * Hd, ss, Q, Q, dh, nb, Hd, scale), s);
+    if (rc) return rc;
+    rc = launch_gemm_f32x(mha_gemm(o0, ldo, os, dh, false, q0 + 2 * Dd, ld, qs, dh, false, dS, Qp, ss * Hd, ss, Q, Q, dh, nb, Hd, 1.0f), s);
+    if (rc) return rc;
+    const long nrows = (long)nb * Hd * Q;
+    hipLaunchKernelGGL(mha_softmax_bwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, Pd, dS, Q, Qp, nrows, (long)b0 * Hd * Q, p, key);
+    if (hipGetLastError() != hipSuccess) return 3;
+    // dq = scale dS k;  dk = scale dS^T q;  dv = Pd^T dO      (k, q, dO enter as the k-major operand: [token, dh] views)
+    rc = launch_gemm_f32x(mha_gemm(dS, Qp, ss * Hd, ss, false, q0 + Dd, ld, qs, dh, true, g0, ld, qs, dh, Q, dh, Q, nb, Hd, scale), s);
+    if (rc) return rc;
+    rc = launch_gemm_f32x(mha_gemm(dS, Qp, ss * Hd, ss, true, q0, ld, qs, dh, true, g0 + Dd, ld, qs, dh, Q, dh, Q, nb, Hd, scale), s);
+    if (rc) return rc;
+    rc = launch_gemm_f32x(mha_gemm(Pd, Qp, ss * Hd, ss, true, o0, ldo, os, dh, true, g0 + 2 * Dd, ld, qs, dh, Q, dh, Q, nb, Hd, 1.0f), s);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ deformable gather backward
