@@ -272,8 +272,11 @@ GemmF32X mha_gemm(const float* A, int lda, long long a_sb, long long a_sh, bool 
 // enough to keep the scores in the 256 MB Infinity Cache between launches were measured and do not pay: ViT-B 518x518, batch 8,
 // one image per pass 23.0 ms per step, two 22.0, the whole batch in one pass 21.7.
 inline int mha_chunk_images(int B, int Hd, int Q) {
+  const char* ei = getenv("DINODET_MHA_CHUNK_IMAGES");          // tests: force several (ragged) passes on small shapes
+  if (ei && atoi(ei) > 0) return atoi(ei) > B ? B : atoi(ei);
+  const char* e = getenv("DINODET_MHA_CHUNK_MB");
+  const size_t mb = e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)1024;
   const size_t per = (size_t)Hd * Q * up4((size_t)Q) * 4;
-  static const size_t mb = [] { const char* e = getenv("DINODET_MHA_CHUNK_MB"); return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)1024; }();
   size_t c = (mb << 20) / (per ? per : 1);
   if (c < 1) c = 1;
   return c > (size_t)B ? B : (int)c;

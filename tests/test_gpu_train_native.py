@@ -89,6 +89,15 @@ def test_native_decoder_backward_matches_composite_autograd(case):
     assert e < gtol
     # the unused reference_points head (detr_decoder.py:44-45) gets no gradient in either path
     assert not any(k.startswith("reference_points.") for k in g1)
+    if B > 1:       # self-attention adjoint in passes of one image (score scratch capped): same forward bit for bit, same gradients
+        os.environ["DINODET_MHA_CHUNK_IMAGES"] = "1"
+        try:
+            l2, b2, dx2, g2 = _run(m, mem, wl, wb, native=True)
+        finally:
+            os.environ.pop("DINODET_MHA_CHUNK_IMAGES", None)
+        assert torch.equal(l2, l1) and torch.equal(b2, b1)
+        for k in g1:        # weight gradients accumulate atomically: equal up to the order of fp32 additions
+            assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 2e-6, k
 
 
 def test_native_decoder_dropout_masks_are_consistent_and_seeded():
@@ -104,6 +113,13 @@ def test_native_decoder_dropout_masks_are_consistent_and_seeded():
     b = nt.decoder_train(m, mem, seed=1234).detach().clone()
     c = nt.decoder_train(m, mem, seed=99).detach().clone()
     assert torch.equal(a, b) and not torch.equal(a, c)
+    # the self-attention runs in passes over image chunks (score scratch capped): the chunking must change nothing, masks included
+    os.environ["DINODET_MHA_CHUNK_IMAGES"] = "3"         # B = 4: passes of 3 + 1 images
+    try:
+        a3 = nt.decoder_train(m, mem, seed=1234).detach().clone()
+    finally:
+        os.environ.pop("DINODET_MHA_CHUNK_IMAGES", None)
+    assert torch.equal(a, a3)
     m.eval()                                             # p = 0 through the same entry
     d = nt.decoder_train(m, mem, seed=1234).detach().clone()
     m.train()
