@@ -165,15 +165,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) { const int k = c * 64 + lane; if (k < D) dxr[k] = rstd * (gv[c] - s1 - xv[c] * s2); }
   }
+  // the workgroup's four waves reduce their parameter-gradient partials in LDS: one atomic per column per workgroup
+  __shared__ float sg[4][MAXC * 64], sb[4][MAXC * 64];
+  const int w = threadIdx.x >> 6;
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int k = c * 64 + lane;
-    if (k < D) { atomicAdd(dgamma + k, dg[c]); atomicAdd(dbeta + k, db[c]); }
+  for (int c = 0; c < MAXC; ++c) { sg[w][c * 64 + lane] = dg[c]; sb[w][c * 64 + lane] = db[c]; }
+  __syncthreads();
+  for (int k = threadIdx.x; k < D; k += 256) {
+    atomicAdd(dgamma + k, (sg[0][k] + sg[1][k]) + (sg[2][k] + sg[3][k]));
+    atomicAdd(dbeta + k, (sb[0][k] + sb[1][k]) + (sb[2][k] + sb[3][k]));
   }
 }
 int ln_bwd(const float* x, const float* gamma, const float* dy, float eps, int rows, int D, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
   if (D > 1024) return 2;
-  int blocks = (rows + 15) / 16; blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+  int blocks = (rows + 3) / 4; blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);      // one row per wave up to 8 192 rows
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, gamma, dy, eps, rows, D, dx, dgamma, dbeta);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
@@ -766,6 +771,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const float* __restrict_
   float acc[LORA_RMAX];
 #pragma unroll
   for (int c = 0; c < LORA_RMAX; ++c) acc[c] = 0.f;
+#pragma unroll 4
   for (int k = lane; k < K; k += 64) {
     const float xv = x[k];
     const float* ak = A + (size_t)k * sa_k;
