@@ -12,7 +12,10 @@ deliberately made non-zero so that every term of the forward is exercised.
 State-dict key names/shapes are those of the reference model
 (SURVEY.md section 8b "State-dict layout").
 """
+import os
 import zlib
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 from .config import BackboneConfig, DecoderConfig
@@ -28,29 +31,67 @@ def _splitmix64(x):
     return z ^ (z >> np.uint64(31))
 
 
-def _stream(seed: int, key: str, n: int, lane: int):
+def _stream(seed: int, key: str, n: int, lane: int, start: int = 0):
     base = np.uint64((seed * 0x100000001B3 + zlib.crc32(key.encode()) * 2 + lane) & 0xFFFFFFFFFFFFFFFF)
     with np.errstate(over="ignore"):
         base = _splitmix64(np.array([base], dtype=np.uint64))[0]
-        idx = np.arange(n, dtype=np.uint64)
+        idx = np.arange(start, start + n, dtype=np.uint64)
         h = _splitmix64(idx * np.uint64(0x2545F4914F6CDD1D) + base)
     return h
+
+
+# Large tensors (a ViT-g state dict is 1.15 G values) are generated in 256 Ki-element chunks on a thread pool: every value is a
+# function of its own index only, numpy's element loops release the GIL, and chunk boundaries are multiples of any vector width
+# (so each element takes the same code path as in a single pass: checked bit for bit in tests/test_oracle_golden.py).
+_CHUNK = 1 << 18
+_POOL = None
+
+
+def _drop_pool():
+    global _POOL
+    _POOL = None            # a forked child has the object but not its threads
+
+
+if hasattr(os, "register_at_fork"):
+    os.register_at_fork(after_in_child=_drop_pool)
+
+
+def _chunked(fn, n):
+    """fn(start, count) -> float32[count]; the concatenation over [0, n)"""
+    if n <= 2 * _CHUNK:
+        return fn(0, n)
+    global _POOL
+    if _POOL is None:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except AttributeError:
+            workers = os.cpu_count() or 1
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(16, workers)))
+    out = np.empty(n, dtype=np.float32)
+
+    def run(s):
+        c = min(_CHUNK, n - s)
+        out[s:s + c] = fn(s, c)
+    list(_POOL.map(run, range(0, n, _CHUNK)))
+    return out
 
 
 def uniform01(seed, key, shape):
     """float32 in [0, 1): top 24 bits of the hash."""
     n = int(np.prod(shape))
-    h = _stream(seed, key, n, 0)
-    return ((h >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(shape)
+    return _chunked(lambda s, c: (_stream(seed, key, c, 0, s) >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24), n).reshape(shape)
 
 
 def normal(seed, key, shape, std=1.0, mean=0.0):
     """Box-Muller in float64 from two hash streams, returned as float32."""
     n = int(np.prod(shape))
-    u1 = ((_stream(seed, key, n, 0) >> np.uint64(11)).astype(np.float64) + 1.0) * (2.0 ** -53)
-    u2 = (_stream(seed, key, n, 1) >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
-    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
-    return (mean + std * z).astype(np.float32).reshape(shape)
+
+    def part(s, c):
+        u1 = ((_stream(seed, key, c, 0, s) >> np.uint64(11)).astype(np.float64) + 1.0) * (2.0 ** -53)
+        u2 = (_stream(seed, key, c, 1, s) >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+        z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+        return (mean + std * z).astype(np.float32)
+    return _chunked(part, n).reshape(shape)
 
 
 def make_pixels(B, H, W, seed=0):

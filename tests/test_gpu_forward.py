@@ -523,8 +523,8 @@ def _full_run(G, variant, precision):
     return res, blocks, cases.golden(name)
 
 
-@pytest.mark.parametrize("variant", ["large", "giant"])
 @pytest.mark.parametrize("precision", GATED)
+@pytest.mark.parametrize("variant", ["large", "giant"])       # the lower decorator varies slowest: one state dict per variant
 def test_full_depth_configs_gated_vs_reference(G, variant, precision):
     """configs[3] ViT-L/14 and configs[4] ViT-g/14 (SwiGLU, 40 blocks) at 518x518 with 300 queries, ALL blocks, one image:
     both parity-gated modes against the REFERENCE's own forward (G7 / G8: modeling_dinov2.py:300-314 at depth, the 1024 /
@@ -545,7 +545,7 @@ def test_full_depth_configs_gated_vs_reference(G, variant, precision):
         assert e < TOL, (k, e)
 
 
-@pytest.mark.parametrize("variant,precision", [("large", "bf16"), ("giant", "bf16"), ("giant", "fp8")])
+@pytest.mark.parametrize("variant,precision", [("giant", "bf16"), ("giant", "fp8"), ("large", "bf16")])   # giant is resident from the test above
 def test_full_depth_configs_throughput_modes(G, variant, precision):
     """The same two configurations in the opt-in throughput modes (configs[3] is quoted in bf16, configs[4] in fp8), full depth.
     Held (a) stage by stage to the oracle evaluated with the SAME operand rounding (tests/golden/emu_*.npz, generated by

@@ -182,3 +182,21 @@ def test_preprocess_oracle_matches_pillow(hw, out):
     assert got.shape == want.shape and np.array_equal(got, want)
     t = ppo.to_tensor(got)
     assert t.shape == (3, out[0], out[1]) and t.dtype == np.float32 and float(t.max()) <= 1.0
+
+
+def test_synthetic_generator_chunked_path_is_bit_identical_to_a_single_pass():
+    """synth generates large tensors in chunks on a thread pool; every value must equal the single-pass evaluation bit for bit
+    (the goldens were generated from the reference with these weights)."""
+    from dinov2_od_amd import synth
+
+    def single_normal(seed, key, n, std):
+        u1 = ((synth._stream(seed, key, n, 0) >> np.uint64(11)).astype(np.float64) + 1.0) * (2.0 ** -53)
+        u2 = (synth._stream(seed, key, n, 1) >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+        return (0.0 + std * (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2))).astype(np.float32)
+
+    for n in (2 * synth._CHUNK, 2 * synth._CHUNK + 1, 5 * synth._CHUNK + 12345):
+        a = synth.normal(1, f"chunk.{n}", (n,), 0.02)
+        assert np.array_equal(a.view(np.uint32), single_normal(1, f"chunk.{n}", n, 0.02).view(np.uint32)), n
+        u = synth.uniform01(3, f"chunk.u.{n}", (n,))
+        want = (synth._stream(3, f"chunk.u.{n}", n, 0) >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+        assert np.array_equal(u, want), n
