@@ -110,16 +110,19 @@ SYMBOLS = {
     "dod_backbone_tail_train_backward": (_I, [C.POINTER(DodConfig), _P, _I, _I, _P, _P, _SZ, _P, _P, _SZ, _P]),
     "dod_reserve_gemm_scratch": (_I, [C.c_size_t]),
     "dod_debug_tail_splits": (C.c_long, []),
+    "dod_debug_set_tailsplit": (None, [_I]),
     "dod_debug_gemm_stamps": (_I, [_P]),
     "dod_debug_pp_stamps": (_I, [_P]),
     "dod_debug_attn_stamps": (_I, [_P]),
     "dod_debug_mfma_peak": (_I, [_I, _I, _I, _P, _P]),
     "dod_debug_mfma_valu_probe": (_I, [_I, _I, _I, _I, _P, _P]),
     "dod_version": (C.c_char_p, []),
+    "dod_abi_version": (_I, []),
     "dod_device_count": (_I, []),
 }
 
 _lib = None
+ABI_VERSION = 3     # include/dinodet.h DOD_ABI_VERSION
 
 
 def lib():
@@ -140,6 +143,9 @@ def lib():
             fn = getattr(L, name)   # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if L.dod_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI revision {L.dod_abi_version()}, this binding expects {ABI_VERSION}: rebuild it "
+                               "(`python -m dinov2_od_amd._build --force`)")
         try:
             if torch.cuda.is_available() and L.dod_device_count() <= 0:
                 raise RuntimeError("libdinodet.so is bound to a different HIP runtime than PyTorch "

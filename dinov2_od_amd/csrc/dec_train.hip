@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void deform_bwd_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ orchestration
-std::string g_terr;
+thread_local std::string g_terr;   // forward and backward of a step may run on different threads (autograd engine)
 int tfail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);

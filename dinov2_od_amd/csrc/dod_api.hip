@@ -811,7 +811,8 @@ int launch_widen_bf16(const bf16_t* in, float* out, size_t n, hipStream_t s) {
 // =========================================================================================== C ABI
 extern "C" {
 
-const char* dod_version(void) { return "dinodet 0.1 (gfx950)"; }
+const char* dod_version(void) { return "dinodet 0.3 (gfx950)"; }
+int dod_abi_version(void) { return DOD_ABI_VERSION; }
 
 int dod_device_count(void) {
   int n = 0;

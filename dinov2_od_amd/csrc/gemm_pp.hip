@@ -19,6 +19,8 @@
 //   * WAR: the LDS reads of a phase are retired (lgkmcnt(0)) BEFORE the barrier that ends the LOAD segment; a plane is
 //     re-staged only after the barrier following group 1's last read of it.  RAW: a plane is read one barrier (at least)
 //     after the barrier that follows every wave's vmcnt wait for it.
+#include <atomic>
+#include <mutex>
 #include "dod_common.h"
 #include "gemm_epi.h"
 #include <cstdlib>
@@ -866,24 +868,30 @@ __global__ __launch_bounds__(512) void gemm_ksplit_reduce_kernel(const float* __
 // micro-batches on separate streams -- engine.py: two -- and a process creates many short-lived streams over time: warm-up, capture,
 // side streams).  Streams that launch concurrently must not share a slab: up to TAIL_SLOTS of them never do.
 #define TAIL_SLOTS 4
-static float* g_tail_scratch[16] = {};
-static size_t g_tail_bytes[16] = {};           // bytes per slab
+#define TAIL_GENS 4                            // the scratch only ever GROWS by adding a block: captured hipGraphs keep slab addresses
+static std::mutex g_tail_mu;                   // autograd / DataLoader threads may launch GEMMs beside the main thread
+static float* g_tail_scratch[16][TAIL_GENS] = {};
+static int g_tail_gen[16] = {};                // blocks allocated so far (the newest one is handed out)
+static size_t g_tail_bytes[16] = {};           // bytes per slab of the newest block
 static hipStream_t g_tail_owner[16][TAIL_SLOTS] = {};
 static unsigned long long g_tail_used[16][TAIL_SLOTS] = {};
 static unsigned long long g_tail_clock = 0;
 int gemm_tail_reserve(size_t bytes) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 3;
+  std::lock_guard<std::mutex> lk(g_tail_mu);
   if (g_tail_bytes[dev] >= bytes) return 0;
-  if (g_tail_scratch[dev]) (void)hipFree(g_tail_scratch[dev]);
-  g_tail_scratch[dev] = nullptr; g_tail_bytes[dev] = 0;
+  if (g_tail_gen[dev] >= TAIL_GENS) return 3;  // never free a block a captured graph may still reference: refuse instead
+  float* blk = nullptr;
+  if (hipMalloc((void**)&blk, bytes * TAIL_SLOTS) != hipSuccess) return 3;
+  g_tail_scratch[dev][g_tail_gen[dev]++] = blk;
   for (int i = 0; i < TAIL_SLOTS; ++i) { g_tail_used[dev][i] = 0; g_tail_owner[dev][i] = nullptr; }
-  if (hipMalloc((void**)&g_tail_scratch[dev], bytes * TAIL_SLOTS) != hipSuccess) return 3;
   g_tail_bytes[dev] = bytes;
   return 0;
 }
 static float* tail_slab(int dev, hipStream_t s) {
-  if (!g_tail_scratch[dev]) return nullptr;
+  std::lock_guard<std::mutex> lk(g_tail_mu);
+  if (!g_tail_gen[dev]) return nullptr;
   int pick = -1;
   for (int i = 0; i < TAIL_SLOTS; ++i)
     if (g_tail_used[dev][i] && g_tail_owner[dev][i] == s) { pick = i; break; }
@@ -894,7 +902,18 @@ static float* tail_slab(int dev, hipStream_t s) {
     g_tail_owner[dev][pick] = s;
   }
   g_tail_used[dev][pick] = ++g_tail_clock;
-  return (float*)((char*)g_tail_scratch[dev] + (size_t)pick * g_tail_bytes[dev]);
+  return (float*)((char*)g_tail_scratch[dev][g_tail_gen[dev] - 1] + (size_t)pick * g_tail_bytes[dev]);
+}
+
+// mode of the split: -1 = DINODET_GEMM_TAILSPLIT from the environment (read once), 0 = off, 1 = the shipped heuristic, 2 = every
+// qualifying shape (tests).  dod_debug_set_tailsplit lets a test force the split for its own cases and hand the default back.
+static std::atomic<int> g_tail_mode{-1};
+extern "C" void dod_debug_set_tailsplit(int mode) { g_tail_mode.store(mode); }
+static int tail_mode() {
+  const int m = g_tail_mode.load();
+  if (m >= 0) return m;
+  static const char* env = getenv("DINODET_GEMM_TAILSPLIT");
+  return env ? (env[0] == '0' ? 0 : (env[0] == '2' ? 2 : 1)) : 1;
 }
 
 static thread_local bool t_in_tail_split = false;
@@ -902,8 +921,8 @@ static long g_tail_splits = 0;
 extern "C" long dod_debug_tail_splits() { return g_tail_splits; }   // tuning / tests: how many GEMM calls took the split path
 int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
   if (t_in_tail_split || e.ksplit > 1 || e.rows_per_img != 0 || e.a_scale || e.out_split > 0) return -1;
-  static const char* off = getenv("DINODET_GEMM_TAILSPLIT");
-  if (off && off[0] == '0') return -1;
+  const int mode = tail_mode();
+  if (mode == 0) return -1;
   const int ktile = kind == 0 ? 64 : 32;
   if (N % 4 != 0 || K % ktile != 0) return -1;
   int dev = 0;
@@ -913,7 +932,7 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   const int CU = cus[dev];
   const int tiles_n = (N + PPN - 1) / PPN, tiles_m = (M + PPM - 1) / PPM, tiles = tiles_m * tiles_n;
   const int nk = K / ktile;
-  const bool force = off && off[0] == '2';
+  const bool force = mode == 2;
   int Mmain, R, tiles_r, S = 0;
   if (kind >= 1 && M >= 2048 && tiles * 2 <= CU + CU / 8) {
     // (a) an UNDERFILLED single round (the compensated kernels have no smaller tile): 99 tiles of an N = 768 GEMM at M = 8224 leave 157

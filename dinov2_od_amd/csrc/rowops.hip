@@ -9,103 +9,138 @@
 // eps 1e-5).  One wave per row, D % 4 == 0, D <= 2048.  Two-pass statistics in registers
 // (mean, then centred variance) like ATen's RowwiseMoments result to fp32 rounding.
 #define LN_MAXC 8
+// Output forms (compile-time: the round-2 kernel took them as runtime pointers / an int and carried every writer's registers -- 100
+// VGPRs, four waves per SIMD -- which cost 27 % of its bandwidth).
+enum { LN_F32 = 1, LN_BF16 = 2, LN_PAIR = 4, LN_H2 = 8, LN_FP8 = 16 };
+struct LnOut { float* f32; bf16_t* bf16; unsigned char* fp8; float* scale; bf16_t* split; };
+// NCH float4 chunks per lane (compile-time trip count: D = 768 holds a row in 3 x 4 registers instead of LN_MAXC x 4); EXACT: D == 256 NCH
+template <int NCH, bool EXACT, int OUT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, int rows, int D, float* __restrict__ out_f32,
-                                                        bf16_t* __restrict__ out_bf16, unsigned char* __restrict__ out_fp8,
-                                                        float* __restrict__ out_scale, bf16_t* __restrict__ out_split3, int h2) {
+                                                        float eps, int rows, int D, LnOut o) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nc = D >> 2;
   const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
   const float4* ar = add ? reinterpret_cast<const float4*>(add + (size_t)row * D) : nullptr;
-  float4 v[LN_MAXC];
+  float4 v[NCH];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
-    if (c < nc) {
-      v[i] = xr[c];
-      if (ar) { const float4 a = ar[c]; v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w; }
-      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    if (EXACT || c < nc) v[i] = xr[c];
+  }
+  if (ar) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (EXACT || c < nc) { const float4 a = ar[c]; v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w; }
     }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (EXACT || c < nc) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
-    if (c < nc) {
+    if (EXACT || c < nc) {
       const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
       q += (a * a + b * b) + (cc * cc + d * d);
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-  if (out_fp8) {   // fp8 operand for the next GEMM: normalised row kept in registers, one scale per row (amax / 448)
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (EXACT || c < nc) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+      const float4 b = reinterpret_cast<const float4*>(beta)[c];
+      v[i].x = (v[i].x - mean) * rstd * g.x + b.x;
+      v[i].y = (v[i].y - mean) * rstd * g.y + b.y;
+      v[i].z = (v[i].z - mean) * rstd * g.z + b.z;
+      v[i].w = (v[i].w - mean) * rstd * g.w + b.w;
+    }
+  }
+  if (OUT & LN_FP8) {   // fp8 operand for the next GEMM: normalised row kept in registers, one scale per row (amax / 448)
     float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
-      if (c < nc) {
-        const float4 g = reinterpret_cast<const float4*>(gamma)[c];
-        const float4 b = reinterpret_cast<const float4*>(beta)[c];
-        v[i].x = (v[i].x - mean) * rstd * g.x + b.x;
-        v[i].y = (v[i].y - mean) * rstd * g.y + b.y;
-        v[i].z = (v[i].z - mean) * rstd * g.z + b.z;
-        v[i].w = (v[i].w - mean) * rstd * g.w + b.w;
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
-      }
+      if (EXACT || c < nc) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
     }
     amax = wave_max(amax);
     const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
     const float inv = 1.0f / sc;
-    if (lane == 0) out_scale[row] = sc;
+    if (lane == 0) o.scale[row] = sc;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
-      if (c < nc) reinterpret_cast<unsigned*>(out_fp8 + (size_t)row * D)[c] = pack4_fp8(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+      if (EXACT || c < nc) reinterpret_cast<unsigned*>(o.fp8 + (size_t)row * D)[c] = pack4_fp8(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
     }
     return;
   }
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
-    if (c < nc) {
-      const float4 g = reinterpret_cast<const float4*>(gamma)[c];
-      const float4 b = reinterpret_cast<const float4*>(beta)[c];
-      float4 o;
-      o.x = (v[i].x - mean) * rstd * g.x + b.x;
-      o.y = (v[i].y - mean) * rstd * g.y + b.y;
-      o.z = (v[i].z - mean) * rstd * g.z + b.z;
-      o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[c] = o;
-      if (out_split3 && h2) {   // H2 operand row (fp16 | e4m3 main, e4m3 remainder per 32-k block; dod_common.h)
+    if (EXACT || c < nc) {
+      const float4 w = v[i];
+      if (OUT & LN_F32) reinterpret_cast<float4*>(o.f32 + (size_t)row * D)[c] = w;
+      if (OUT & LN_H2) {   // H2 operand row (fp16 | e4m3 main, e4m3 remainder per 32-k block; dod_common.h)
         uint2 f16; unsigned hi8, lo8;
-        h2_quad(o, 1.0f, f16, hi8, lo8);
-        char* ob = reinterpret_cast<char*>(out_split3) + (size_t)row * 4 * D;
+        h2_quad(w, 1.0f, f16, hi8, lo8);
+        char* ob = reinterpret_cast<char*>(o.split) + (size_t)row * 4 * D;
         reinterpret_cast<uint2*>(ob)[c] = f16;
         char* p8 = ob + h2_off8(D, 4 * c);
         *reinterpret_cast<unsigned*>(p8) = hi8;
         *reinterpret_cast<unsigned*>(p8 + 16) = lo8;
-      } else if (out_split3) {   // split-product operand in the pair layout [hi | lo] (row pitch 2*D)
+      }
+      if (OUT & LN_PAIR) {   // split-product operand in the pair layout [hi | lo] (row pitch 2*D)
         uint2 hi, lo;
-        hi.x = pack2bf(o.x, o.y);
-        hi.y = pack2bf(o.z, o.w);
-        lo.x = pack2bf(o.x - __uint_as_float(hi.x << 16), o.y - __uint_as_float(hi.x & 0xffff0000u));
-        lo.y = pack2bf(o.z - __uint_as_float(hi.y << 16), o.w - __uint_as_float(hi.y & 0xffff0000u));
-        bf16_t* ob = out_split3 + (size_t)row * 2 * D;
+        hi.x = pack2bf(w.x, w.y);
+        hi.y = pack2bf(w.z, w.w);
+        lo.x = pack2bf(w.x - __uint_as_float(hi.x << 16), w.y - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = pack2bf(w.z - __uint_as_float(hi.y << 16), w.w - __uint_as_float(hi.y & 0xffff0000u));
+        bf16_t* ob = o.split + (size_t)row * 2 * D;
         reinterpret_cast<uint2*>(ob)[c] = hi;
         reinterpret_cast<uint2*>(ob + D)[c] = lo;
       }
-      if (out_bf16) {
+      if (OUT & LN_BF16) {
         uint2 p;
-        p.x = pack2bf(o.x, o.y);
-        p.y = pack2bf(o.z, o.w);
-        reinterpret_cast<uint2*>(out_bf16 + (size_t)row * D)[c] = p;
+        p.x = pack2bf(w.x, w.y);
+        p.y = pack2bf(w.z, w.w);
+        reinterpret_cast<uint2*>(o.bf16 + (size_t)row * D)[c] = p;
       }
     }
   }
+}
+
+template <int OUT>
+static void ln_dispatch(const float* x, const float* add, const float* gamma, const float* beta, float eps, int rows, int D,
+                        const LnOut& o, hipStream_t s) {
+  const dim3 grid((rows + 3) / 4), block(256);
+  const int nc = D >> 2, nch = (nc + 63) / 64;
+  const bool exact = nc == 64 * nch;
+#define LN_GO(N, E) hipLaunchKernelGGL((layernorm_kernel<N, E, OUT>), grid, block, 0, s, x, add, gamma, beta, eps, rows, D, o)
+  if (exact) {
+    switch (nch) {
+      case 1: LN_GO(1, true); return;
+      case 2: LN_GO(2, true); return;
+      case 3: LN_GO(3, true); return;     // D = 768 (ViT-B, the decoder)
+      case 4: LN_GO(4, true); return;     // D = 1024 (ViT-L)
+      case 6: LN_GO(6, true); return;     // D = 1536 (ViT-g)
+      default: break;
+    }
+  }
+  if (nch <= 1) LN_GO(1, false);
+  else if (nch <= 2) LN_GO(2, false);     // D = 384 (ViT-S)
+  else if (nch <= 4) LN_GO(4, false);
+  else LN_GO(LN_MAXC, false);
+#undef LN_GO
 }
 
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
@@ -115,8 +150,14 @@ int launch_layernorm(const float* x, const float* add, const float* gamma, const
   if (D % 4 != 0 || D > 256 * LN_MAXC) return 2;
   if (h2 && (!out_split3 || D % 32 != 0)) return 2;
   if ((out_fp8 == nullptr) != (out_scale == nullptr)) return 2;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, add, gamma, beta, eps, rows, D,
-                     out_f32, out_bf16, out_fp8, out_scale, out_split3, h2);
+  LnOut o{out_f32, out_bf16, out_fp8, out_scale, out_split3};
+  if (out_fp8) ln_dispatch<LN_FP8>(x, add, gamma, beta, eps, rows, D, o, s);
+  else if (out_split3 && (out_f32 || out_bf16)) return 2;
+  else if (out_split3) { if (h2) ln_dispatch<LN_H2>(x, add, gamma, beta, eps, rows, D, o, s); else ln_dispatch<LN_PAIR>(x, add, gamma, beta, eps, rows, D, o, s); }
+  else if (out_f32 && out_bf16) ln_dispatch<LN_F32 | LN_BF16>(x, add, gamma, beta, eps, rows, D, o, s);
+  else if (out_bf16) ln_dispatch<LN_BF16>(x, add, gamma, beta, eps, rows, D, o, s);
+  else if (out_f32) ln_dispatch<LN_F32>(x, add, gamma, beta, eps, rows, D, o, s);
+  else return 2;
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -212,6 +212,10 @@ class Engine:
         wss, side = st
         det = torch.empty(B, self.dc.num_queries, self.dc.num_classes + 4, dtype=torch.float32, device=x.device)
         cur = torch.cuda.current_stream(x.device)
+        # the (H, W) position table is built (hipMalloc + resize kernel) by the first forward at a new grid, on the stream of THAT
+        # launch: done here on `cur`, before the fork, so that the side streams' patch embeds are ordered behind the resize kernel
+        # (a cache hit is a host-side lookup)
+        nat.check(self._lib.dod_prepare(self._h, H, W, nat.stream_ptr()), self._h)
         for sd in side:
             sd.wait_stream(cur)                              # fork: x (and det's allocation) are ready on `cur`
         self._launch_forward(x[:sizes[0]], wss[0], det[:sizes[0]])

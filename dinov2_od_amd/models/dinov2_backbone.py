@@ -120,15 +120,20 @@ class _EngineMixin:
 
     def _engine_named(self):
         """list of (reference state-dict key, tensor).  Built once (a state_dict() walk of 300+ entries per forward costs
-        more than a small-batch forward does) and dropped by anything that can replace tensors: _apply (.to / .cuda /
-        .float), load_state_dict, or a call of invalidate_weight_cache() after swapping parameters by hand.  In-place
+        more than a small-batch forward does), dropped by _apply (.to / .cuda / .float), load_state_dict and
+        invalidate_weight_cache(), and rebuilt whenever a Parameter object of the tree was replaced.  In-place
         updates (optimizer steps, load_state_dict's copy_) keep the list valid and are seen by the engine's
         (data_ptr, _version) signature."""
-        named = self.__dict__.get("_named_cache")
-        if named is None:
-            named = [(self._key_prefix + k, v) for k, v in self.state_dict(keep_vars=True).items()]
-            self.__dict__["_named_cache"] = named
-        return named
+        # the cache is validated against the identity of the module tree's current Parameter objects (an id() walk: ~20x cheaper
+        # than state_dict()): add_lora_to_module / setattr of a block / register_parameter / load_state_dict(assign=True) on a child
+        # replace objects without passing through the hooks below, and the (data_ptr, _version) signature of the OLD tensors would
+        # still match
+        ids = tuple(id(p) for p in self.parameters())
+        ent = self.__dict__.get("_named_cache")
+        if ent is None or ent[0] != ids:
+            ent = (ids, [(self._key_prefix + k, v) for k, v in self.state_dict(keep_vars=True).items()])
+            self.__dict__["_named_cache"] = ent
+        return ent[1]
 
     def invalidate_weight_cache(self):
         self.__dict__.pop("_named_cache", None)

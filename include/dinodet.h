@@ -321,6 +321,9 @@ int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_pa
  * current device; operator-level callers (tests, tools) reserve it themselves.  Never allocated inside a forward / stream capture. */
 int dod_reserve_gemm_scratch(size_t bytes);
 long dod_debug_tail_splits(void);   /* number of GEMM calls that took the tail-split path so far (tests) */
+/* mode of the tail split: -1 the DINODET_GEMM_TAILSPLIT environment default (the shipped heuristic when unset), 0 off, 1 heuristic,
+ * 2 every qualifying shape (tests force it for their own cases and hand -1 back) */
+void dod_debug_set_tailsplit(int mode);
 int dod_debug_gemm_stamps(void* dev_buf);
 /* same for the ping-pong kernels (gemm_pp.hip): 8 x uint64 per workgroup, shader cycles (tools/pp_timeline.py) */
 int dod_debug_pp_stamps(void* dev_buf);
@@ -335,6 +338,10 @@ int dod_debug_mfma_peak(int shape, int iters, int blocks, void* dev_out, void* s
 int dod_debug_mfma_valu_probe(int nvalu, int mode, int iters, int blocks, void* dev_out, void* stream);
 
 const char* dod_version(void);
+/* ABI revision of this header: bumped whenever an exported signature or struct layout changes (round 2's dod_set_weight gained its
+ * dtype argument at revision 2; revision 3 = this file).  A C caller compiled against DOD_ABI_VERSION checks it once at load. */
+#define DOD_ABI_VERSION 3
+int dod_abi_version(void);
 /* Devices visible to the HIP runtime libdinodet.so is bound to (<= 0: none / error).  The host uses it to
  * verify the library shares PyTorch's HIP runtime (pointers and streams cross this ABI). */
 int dod_device_count(void);

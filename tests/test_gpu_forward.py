@@ -330,6 +330,24 @@ def test_concurrent_micro_batches_are_bit_identical(G, precision):
     m.enable_hipgraph(False)
 
 
+def test_first_forward_at_a_resized_grid_through_the_micro_path(G):
+    """the (H, W) position table is built by the first forward at a new grid (hipMalloc + resize kernel on the launch stream).  When
+    that first forward is split into concurrent micro-batches, the table must be ordered before the fork: the side stream's patch
+    embed reads it (engine._launch_micro calls dod_prepare on the current stream first).  Fresh engines, non-native grids."""
+    bb, dc = cases.cfg1(25)
+    for H, W in ((112, 168), (224, 224), (70, 98)):
+        x = G.to_gpu(synth.make_pixels(6, H, W, seed=4))
+        ref = G.make_detector(bb, dc, "bf16x3", "facebook/dinov2-small")
+        ref._get_engine().micro_streams = 1
+        want = ref.forward_packed(x).clone()
+        m = G.make_detector(bb, dc, "bf16x3", "facebook/dinov2-small")          # cold position cache
+        eng = m._get_engine()
+        eng.micro_streams, eng.micro_min_batch, eng.micro_min_rows = 2, 2, 0
+        got = m.forward_packed(x)                                                # FIRST call at (H, W): micro path
+        G.sync()
+        assert torch.equal(got, want), (H, W)
+
+
 def test_hipgraph_small_shape_survives_a_later_larger_one(G):
     """a captured graph bakes in the address of its workspace: a later, larger shape (or an eager call that needs more scratch)
     must not pull it from under the earlier graph.  Capture small, then large, run eager calls of other shapes, replay small."""

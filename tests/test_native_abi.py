@@ -127,3 +127,28 @@ def test_forward_without_gpu_fails_loudly():
     m.train()                      # train(): the autograd composite is GPU-only too
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 3, 224, 224))
+
+
+def test_engine_named_cache_follows_replaced_parameters():
+    """_engine_named() caches the (key, tensor) list; replacing a Parameter object after the first call (setattr of a block,
+    register_parameter, load_state_dict(assign=True) on a child) must be seen -- the engine's (data_ptr, _version) signature of the
+    OLD tensors would still match.  Host logic only."""
+    from dinov2_od_amd.models import DINOv2ObjectDetector
+    m = DINOv2ObjectDetector(dino_model_name="facebook/dinov2-small", hidden_dim=64, num_queries=5, num_decoder_layers=1,
+                             dim_feedforward=64, lora_r=1, nheads=4, pretrained=False)
+    a = dict(m._engine_named())
+    assert m._engine_named() is m._engine_named()                      # cached
+    key = "decoder.class_embed.weight"
+    new = torch.nn.Parameter(torch.zeros_like(m.decoder.class_embed.weight))
+    m.decoder.class_embed.weight = new                                  # no hook of the mixin sees this
+    b = dict(m._engine_named())
+    assert b[key] is new and a[key] is not new
+    sd = {k: v.clone() for k, v in m.decoder.state_dict().items()}
+    m.decoder.load_state_dict(sd, assign=True)                          # child-level assign: every tensor object replaced
+    c = dict(m._engine_named())
+    assert all(c["decoder." + k] is v for k, v in m.decoder.state_dict(keep_vars=True).items())
+
+
+def test_abi_version_matches_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "dinodet.h")).read()
+    assert int(re.search(r"#define DOD_ABI_VERSION (\d+)", hdr).group(1)) == lib.dod_abi_version() == nat.ABI_VERSION
