@@ -112,6 +112,26 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __res
 __global__ void gelu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ h, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) h[i] = gelu_erf(pre[i]);
 }
+// SwiGLU (Dinov2SwiGLUFFN, modeling_dinov2.py:300-314): pre [rows, 2F] = [x1 | x2] -> h = silu(x1) * x2
+__global__ void swiglu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ h, size_t rows, int F) {
+  const size_t n = rows * (size_t)F;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / F; const int c = (int)(i - r * F);
+    const float x1 = pre[r * 2 * F + c], x2 = pre[r * 2 * F + F + c];
+    h[i] = x1 / (1.0f + expf(-x1)) * x2;
+  }
+}
+// its adjoint: d(x1) = dh x2 s (1 + x1 (1 - s)), d(x2) = dh x1 s, s = sigmoid(x1); written as [d(x1) | d(x2)] rows of 2F
+__global__ void swiglu_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ pre, float* __restrict__ dpre, size_t rows, int F) {
+  const size_t n = rows * (size_t)F;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / F; const int c = (int)(i - r * F);
+    const float x1 = pre[r * 2 * F + c], x2 = pre[r * 2 * F + F + c], g = dh[i];
+    const float sg = 1.0f / (1.0f + expf(-x1));
+    dpre[r * 2 * F + c] = g * x2 * sg * (1.0f + x1 * (1.0f - sg));
+    dpre[r * 2 * F + F + c] = g * x1 * sg;
+  }
+}
 // out[i] = a[i] * v[i % D]   (LayerScale on the gradient)
 __global__ void colscale_kernel(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ out, size_t n, int D) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] * v[i % D];
@@ -710,17 +730,19 @@ int dod_decoder_train_backward(const dod_config* cfg, const dod_dec_train_params
 // (dinov2_backbone.py:33-37, 64-65) in train() mode -- the rest of what `loss.backward()` (train.py:1101) reaches: gradients of every
 // lora_A / lora_B (utils.py:46-70) and of the projection.  The DINOv2 weights, LayerNorms, LayerScales and biases are frozen
 // (dinov2_backbone.py:40-41), and so is everything in front of the first adapted block (it runs in the inference kernels,
-// dod_backbone_prefix): the backward stops at the tail's input.  GELU MLP (ViT-S/B/L).
+// dod_backbone_prefix): the backward stops at the tail's input.  GELU MLP (ViT-S/B/L) or SwiGLU (ViT-g: modeling_dinov2.py:300-314; the
+// fc1 / fc2 slots of dod_bb_block_params then hold mlp.weights_in [2F, D] / mlp.weights_out [D, F]).
 //   forward : x -> LN1 -> q|k|v (W' = W + alpha B A, merged in fp32 as the eval path does) -> softmax(q k^T / sqrt(dh)) v -> dense
 //             -> x + ls1 * . -> LN2 -> fc1 -> GELU(erf) -> fc2 -> + ls2 * .  ->  final LN -> projection
 //   backward: dX = dY W' on the fp32 MFMA GEMM; per LoRA linear  dB += alpha dY^T (X A^T),  dA += alpha (dY B)^T X  (rank-r GEMMs);
 //             attention backward = the row / column passes of the decoder's self-attention with Q := N tokens.
 namespace {
 
-struct TDims { int B, N, M, D, H, dh, F, Dd, nb, r; float alpha, eps; };
+struct TDims { int B, N, M, D, H, dh, F, F1, Dd, nb, r, swiglu; float alpha, eps; };   // F1: width of the first MLP linear (2F for SwiGLU)
 bool make_tdims(const dod_config* c, int B, int N, int nblocks, TDims* d) {
-  if (!c || B <= 0 || N <= 0 || nblocks <= 0 || nblocks > 8 || c->swiglu) return false;
+  if (!c || B <= 0 || N <= 0 || nblocks <= 0 || nblocks > 8) return false;
   d->B = B; d->N = N; d->M = B * N; d->D = c->hidden; d->H = c->heads; d->dh = d->D / d->H; d->F = c->ffn_hidden;
+  d->swiglu = c->swiglu ? 1 : 0; d->F1 = c->swiglu ? 2 * c->ffn_hidden : c->ffn_hidden;
   d->Dd = c->target_dim ? c->target_dim : c->hidden; d->nb = nblocks; d->r = c->lora_r; d->alpha = c->lora_alpha; d->eps = c->ln_eps;
   if (d->D % d->H || d->dh > 128 || d->dh % 4 || d->D % 4 || d->F % 4 || d->D > 1024 * 16 || N > MHA_MAXQ || d->r < 1 || d->r > 64) return false;
   return true;
@@ -738,21 +760,22 @@ size_t carve_ttape(const TDims& d, void* base, TTape* t) {
   for (int i = 0; i < d.nb; ++i) {
     auto& b = tt.b[i];
     b.x = take(M * D); b.y1 = take(M * D); b.qkv = take(M * 3 * D); b.ctx = take(M * D); b.x1 = take(M * D); b.y2 = take(M * D);
-    b.pre = take(M * F); b.h = take(M * F);
-    b.Wqkv = take(3 * D * D); b.Wo = take(D * D); b.W1 = take(F * D); b.W2 = take(D * F); b.bqkv = take(3 * D);
+    b.pre = take(M * (size_t)d.F1); b.h = take(M * F);
+    b.Wqkv = take(3 * D * D); b.Wo = take(D * D); b.W1 = take((size_t)d.F1 * D); b.W2 = take(D * F); b.bqkv = take(3 * D);
   }
   if (t) *t = tt;
   return off;
 }
-struct TScratch { float *dx, *da, *db, *dbig, *dqkv, *dS, *Pd, *T, *U, *dump; };
+struct TScratch { float *dx, *da, *db, *dbig, *dqkv, *dS, *Pd, *T, *U, *dump, *dh; };
 size_t carve_tscratch(const TDims& d, void* base, TScratch* sc) {
   size_t off = 0;
   auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr; off += al256(n * 4); return p; };
-  const size_t M = d.M, D = d.D, F = d.F, big = F > 3 * D ? F : 3 * D;
+  const size_t M = d.M, D = d.D, F = d.F1, big = F > 3 * D ? F : 3 * D;
   TScratch s;
   s.dx = take(M * D); s.da = take(M * D); s.db = take(M * D); s.dbig = take(M * big); s.dqkv = take(M * 3 * D);
   s.dS = take(mha_scratch_floats(d.B, d.H, d.N)); s.Pd = take(mha_scratch_floats(d.B, d.H, d.N));
   s.T = take(M * up4(d.r)); s.U = take(M * up4(d.r)); s.dump = take(2 * big);
+  s.dh = d.swiglu ? take(M * (size_t)d.F) : nullptr;        // SwiGLU: d(h) [M, F] beside d(pre) [M, 2F] (the tape stays read-only)
   if (sc) *sc = s;
   return off;
 }
@@ -856,7 +879,7 @@ int dod_backbone_tail_train_forward(const dod_config* cfg, const dod_bb_tail_par
                                     void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
   if (!p || !p->blocks) return tfail(DOD_ERR_INVALID, "backbone tail: null parameters");
   TDims d;
-  if (!make_tdims(cfg, B, N, p->nblocks, &d)) return tfail(DOD_ERR_INVALID, "backbone tail: unsupported configuration (GELU MLP, head_dim <= 128, N <= %d, 1 <= lora_r <= 64)", MHA_MAXQ);
+  if (!make_tdims(cfg, B, N, p->nblocks, &d)) return tfail(DOD_ERR_INVALID, "backbone tail: unsupported configuration (head_dim <= 128, N <= %d, 1 <= lora_r <= 64, at most 8 blocks)", MHA_MAXQ);
   if (!x_in || !mem_out || !tape || !ws) return tfail(DOD_ERR_INVALID, "backbone tail: null buffer");
   if (tape_bytes < dod_backbone_tail_tape_bytes(cfg, B, N, p->nblocks) || ws_bytes < dod_backbone_tail_workspace_bytes(cfg, B, N, p->nblocks))
     return tfail(DOD_ERR_STATE, "backbone tail: tape / workspace too small");
@@ -865,7 +888,7 @@ int dod_backbone_tail_train_forward(const dod_config* cfg, const dod_bb_tail_par
   TTape t; TScratch sc;
   carve_ttape(d, (void*)(((uintptr_t)tape + 255) & ~(uintptr_t)255), &t);
   carve_tscratch(d, (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &sc);
-  const int M = d.M, D = d.D, F = d.F;
+  const int M = d.M, D = d.D, F = d.F, F1 = d.F1;
   const float scale = 1.0f / sqrtf((float)d.dh);
   TH(hipMemcpyAsync(t.b[0].x, x_in, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
   for (int i = 0; i < d.nb; ++i) {
@@ -878,7 +901,7 @@ int dod_backbone_tail_train_forward(const dod_config* cfg, const dod_bb_tail_par
       TH(hipMemcpyAsync(tb.bqkv + (size_t)c * D, qkv3[c]->b, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
     }
     TK(launch_lora_merge(bp.o.w, bp.o.A, bp.o.Bm, d.alpha, D, D, d.r, tb.Wo, s));
-    TK(launch_lora_merge(bp.fc1.w, bp.fc1.A, bp.fc1.Bm, d.alpha, F, D, d.r, tb.W1, s));
+    TK(launch_lora_merge(bp.fc1.w, bp.fc1.A, bp.fc1.Bm, d.alpha, F1, D, d.r, tb.W1, s));
     TK(launch_lora_merge(bp.fc2.w, bp.fc2.A, bp.fc2.Bm, d.alpha, D, F, d.r, tb.W2, s));
     TK(launch_layernorm(tb.x, nullptr, bp.ln1_w, bp.ln1_b, d.eps, M, D, tb.y1, nullptr, s));
     TK(lin_fwd(tb.y1, D, tb.Wqkv, tb.bqkv, M, 3 * D, D, tb.qkv, 3 * D, ACT_NONE, s));
@@ -892,10 +915,12 @@ int dod_backbone_tail_train_forward(const dod_config* cfg, const dod_bb_tail_par
       TK(launch_gemm_f32(tb.ctx, D, tb.Wo, D, M, D, D, e, s));
     }
     TK(launch_layernorm(tb.x1, nullptr, bp.ln2_w, bp.ln2_b, d.eps, M, D, tb.y2, nullptr, s));
-    TK(lin_fwd(tb.y2, D, tb.W1, bp.fc1.b, M, F, D, tb.pre, F, ACT_NONE, s));        // taped: the backward needs the pre-activation
+    TK(lin_fwd(tb.y2, D, tb.W1, bp.fc1.b, M, F1, D, tb.pre, F1, ACT_NONE, s));      // taped: the backward needs the pre-activation
     {
       const size_t n = (size_t)M * F;
-      hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, tb.pre, tb.h, n);
+      const dim3 grid((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096));
+      if (d.swiglu) hipLaunchKernelGGL(swiglu_fwd_kernel, grid, dim3(256), 0, s, tb.pre, tb.h, (size_t)M, F);   // fc1 / fc2 = weights_in / weights_out
+      else hipLaunchKernelGGL(gelu_fwd_kernel, grid, dim3(256), 0, s, tb.pre, tb.h, n);
       TH(hipGetLastError());
     }
     float* xnext = i + 1 < d.nb ? t.b[i + 1].x : t.xout;
@@ -926,7 +951,7 @@ int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_pa
   carve_ttape(d, (void*)(((uintptr_t)tape + 255) & ~(uintptr_t)255), &t);
   carve_tscratch(d, (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &sc);
   auto G = [](const float* q) { return const_cast<float*>(q); };
-  const int M = d.M, D = d.D, F = d.F;
+  const int M = d.M, D = d.D, F = d.F, F1 = d.F1;
   const size_t nMD = (size_t)M * D;
   const float scale = 1.0f / sqrtf((float)d.dh);
   auto blocks_for = [](size_t n) { return dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)); };
@@ -947,11 +972,16 @@ int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_pa
     hipLaunchKernelGGL(colscale_kernel, blocks_for(nMD), dim3(256), 0, s, sc.dx, bp.ls2, sc.da, nMD, D);                  // da = d(fc2 out)
     TH(hipGetLastError());
     TK(lora_grads(d, tb.h, F, sc.da, D, D, bp.fc2.A, bp.fc2.Bm, G(gp.fc2.A), G(gp.fc2.Bm), sc, s));
-    TK(lin_bwd_x(sc.da, D, tb.W2, M, D, F, sc.dbig, false, s));                                                       // d(h)
-    hipLaunchKernelGGL(gelu_bwd_kernel, blocks_for((size_t)M * F), dim3(256), 0, s, sc.dbig, tb.pre, sc.dbig, (size_t)M * F);
+    if (d.swiglu) {     // d(h) [M, F], then d(pre) = [d(x1) | d(x2)] in dbig
+      TK(lin_bwd_x(sc.da, D, tb.W2, M, D, F, sc.dh, false, s));
+      hipLaunchKernelGGL(swiglu_bwd_kernel, blocks_for((size_t)M * F), dim3(256), 0, s, sc.dh, tb.pre, sc.dbig, (size_t)M, F);
+    } else {
+      TK(lin_bwd_x(sc.da, D, tb.W2, M, D, F, sc.dbig, false, s));                                                     // d(h)
+      hipLaunchKernelGGL(gelu_bwd_kernel, blocks_for((size_t)M * F), dim3(256), 0, s, sc.dbig, tb.pre, sc.dbig, (size_t)M * F);
+    }
     TH(hipGetLastError());
-    TK(lora_grads(d, tb.y2, D, sc.dbig, F, F, bp.fc1.A, bp.fc1.Bm, G(gp.fc1.A), G(gp.fc1.Bm), sc, s));
-    TK(lin_bwd_x(sc.dbig, F, tb.W1, M, F, D, sc.da, false, s));                                                       // d(y2)
+    TK(lora_grads(d, tb.y2, D, sc.dbig, F1, F1, bp.fc1.A, bp.fc1.Bm, G(gp.fc1.A), G(gp.fc1.Bm), sc, s));
+    TK(lin_bwd_x(sc.dbig, F1, tb.W1, M, F1, D, sc.da, false, s));                                                     // d(y2)
     TK(ln_bwd(tb.x1, bp.ln2_w, sc.da, d.eps, M, D, sc.db, sc.dump, sc.dump + D, s));
     TK(add_inplace(sc.dx, sc.db, nMD, s));                                                                                // dx = d(x1)
     // x1 = x + ls1 * (ctx Wo'^T + bo)

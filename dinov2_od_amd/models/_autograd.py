@@ -111,22 +111,20 @@ def decoder_forward(m, src):
     dc = m._dc_cfg
     B, N, Dd = src.shape
     Q, Hd, P = dc.num_queries, dc.nheads, dc.n_points
-    p, tr = m._dropout_p, m.training
-    drop = lambda t: F.dropout(t, p, tr)
     tgt = m.query_embed.weight.unsqueeze(0).repeat(B, 1, 1)
     if m.use_deformable:
         h, w = spatial_factor(N)
         for layer in m.decoder.layers:
             q = tgt.transpose(0, 1)
-            tgt = layer.norm1(tgt + drop(layer.self_attn(q, q, q)[0].transpose(0, 1)))
+            tgt = layer.norm1(tgt + layer.dropout1(layer.self_attn(q, q, q)[0].transpose(0, 1)))
             ref = layer.reference_points_proj(tgt).sigmoid()
             ca = layer.cross_attn
             off = ca.sampling_offsets(tgt).view(B, Q, Hd, P, 2)
             aw = ca.attention_weights(tgt).view(B, Q, Hd, P).softmax(-1)
             val = ca.value_proj(src).view(B, N, Hd, Dd // Hd)
             samp = deformable_sample(val, ref, off, aw, h, w).reshape(B, Q, Dd)
-            tgt = layer.norm2(tgt + drop(ca.output_proj(samp)))
-            tgt = layer.norm3(tgt + drop(layer.linear2(drop(F.relu(layer.linear1(tgt))))))
+            tgt = layer.norm2(tgt + layer.dropout2(ca.output_proj(samp)))
+            tgt = layer.norm3(tgt + layer.dropout4(layer.linear2(layer.dropout3(F.relu(layer.linear1(tgt))))))
         hs = tgt
     else:
         hs = m.decoder(tgt.permute(1, 0, 2), src.permute(1, 0, 2)).transpose(0, 1)

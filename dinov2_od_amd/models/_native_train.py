@@ -32,6 +32,16 @@ def _param_list(m):
             ca.value_proj.weight, ca.value_proj.bias, ca.output_proj.weight, ca.output_proj.bias]
 
 
+def dropout_rate(m):
+    """the ONE rate the native step applies at the reference's five sites (deformable_attention.py:195-209, 235, 261, 265-266), read
+    from the layer's own modules -- each site counts as 0 when its module is in eval() -- or None when the sites disagree (a caller
+    changed one `.p` or put a single sub-module in eval(): the composite, which calls the modules themselves, handles that)"""
+    L = m.decoder.layers[0]
+    rates = {float(d.p) if d.training else 0.0 for d in (L.dropout1, L.dropout2, L.dropout3, L.dropout4)}
+    rates.add(float(L.self_attn.dropout) if L.self_attn.training else 0.0)
+    return rates.pop() if len(rates) == 1 else None
+
+
 def supported(m, src):
     """deformable branch with tied layers (the reference's only form), fp32 CUDA tensors, shapes the kernels take"""
     if not (m.use_deformable and src.is_cuda and src.dtype == torch.float32):
@@ -39,11 +49,11 @@ def supported(m, src):
     layers = list(m.decoder.layers)
     if any(l is not layers[0] for l in layers):
         return False
-    dc = m._dc_cfg
-    dh = dc.hidden_dim // dc.nheads
-    return (dc.hidden_dim % dc.nheads == 0 and dh <= 128 and dh % 4 == 0 and dc.hidden_dim <= 1024 and dc.hidden_dim % 8 == 0
-            and dc.dim_feedforward % 4 == 0 and dc.num_queries <= 1024 and 1 <= dc.n_points <= 8
-            and all(p.is_cuda and p.dtype == torch.float32 for p in _param_list(m)))
+    if not all(p.is_cuda and p.dtype == torch.float32 for p in _param_list(m)) or src.dim() != 3 or dropout_rate(m) is None:
+        return False
+    # the shape limits are the native side's own (make_dims in dec_train.hip): 0 bytes = not taken -> the composite runs instead
+    cfg = make_config(m._bb_cfg, m._dc_cfg, "fp32")
+    return nat.lib().dod_decoder_train_tape_bytes(C.byref(cfg), int(src.shape[0]), int(src.shape[1])) > 0
 
 
 def _struct(tensors):
@@ -102,8 +112,7 @@ def decoder_train(m, src, seed=None):
         # one draw of torch's generator per call (so torch.manual_seed governs the masks), mixed with a call counter
         _seed_counter[0] += 1
         seed = (int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) << 20) ^ _seed_counter[0]
-    p = m._dropout_p if m.training else 0.0
-    return _DecoderTrain.apply(src, cfg, p, seed, *_param_list(m))
+    return _DecoderTrain.apply(src, cfg, dropout_rate(m), seed, *_param_list(m))
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -112,17 +121,22 @@ _LORA_SITES = ("q", "k", "v", "o", "fc1", "fc2")
 
 
 def _tail_modules(layer):
+    """the six LoRA-wrapped linears of a block in the order of _LORA_SITES; a SwiGLU block (ViT-g, modeling_dinov2.py:300-314) puts
+    mlp.weights_in / mlp.weights_out in the fc1 / fc2 slots"""
     a = layer.attention
-    return [a.attention.query, a.attention.key, a.attention.value, a.output.dense, layer.mlp.fc1, layer.mlp.fc2]
+    mlp = (layer.mlp.fc1, layer.mlp.fc2) if hasattr(layer.mlp, "fc1") else (layer.mlp.weights_in, layer.mlp.weights_out)
+    return [a.attention.query, a.attention.key, a.attention.value, a.output.dense, *mlp]
 
 
 def tail_supported(m, layers, x):
-    """every remaining block carries LoRA on its six linears over a frozen base, nothing else in it trains, GELU MLP, fp32 on the GPU"""
+    """every remaining block carries LoRA on its six linears over a frozen base, nothing else in it trains, fp32 on the GPU -- and the
+    native side takes the shape (dod_backbone_tail_tape_bytes > 0 is the kernels' own check: head_dim, token count, rank, depth), so
+    that an unsupported configuration falls back to the autograd composite instead of raising"""
     bb = m._bb_cfg
-    if not (x.is_cuda and x.dtype == torch.float32 and layers and not bb.swiglu and 1 <= bb.lora_r <= 64 and x.shape[1] <= 1408):
+    if not (x.is_cuda and x.dtype == torch.float32 and layers):
         return False
     for L in layers:
-        if not hasattr(L.mlp, "fc1"):
+        if not (hasattr(L.mlp, "fc1") or hasattr(L.mlp, "weights_in")):
             return False
         mods = _tail_modules(L)
         if not all(hasattr(t, "lora_A") for t in mods):
@@ -133,7 +147,9 @@ def tail_supported(m, layers, x):
             return False
     if any(q.requires_grad for q in m.dino.layernorm.parameters()):
         return False
-    return True
+    from ..config import DecoderConfig
+    cfg = make_config(bb, getattr(m, "_dc_cfg", None) or DecoderConfig(), "fp32")
+    return nat.lib().dod_backbone_tail_tape_bytes(C.byref(cfg), int(x.shape[0]), int(x.shape[1]), len(layers)) > 0
 
 
 def _tail_structs(m, layers, train_tensors, writable):

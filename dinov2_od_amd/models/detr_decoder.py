@@ -32,11 +32,16 @@ class DeformableDecoderLayer(_Box):
     def __init__(self, d_model=256, n_heads=8, dim_feedforward=2048, dropout=0.1, n_points=4):
         super().__init__()
         self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
-        self.norm1 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)       # the reference's own dropout modules (deformable_attention.py:196-209): callers that
+        self.norm1 = nn.LayerNorm(d_model)        # change `.p` or put a sub-module in eval() are honoured by the train() paths
         self.cross_attn = DeformableAttention(d_model, n_heads, n_points)
+        self.dropout2 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.activation = nn.ReLU()
+        self.dropout3 = nn.Dropout(dropout)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
         self.reference_points_proj = nn.Linear(d_model, 2)
 

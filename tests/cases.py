@@ -78,3 +78,46 @@ def probe(a):
     """the probe slice make_goldens._probe stores for a [B, N, D] activation"""
     a = np.asarray(a)
     return a[:, ::max(1, a.shape[1] // 8), :64]
+
+
+# ------------------------------------------------------------------------------------------------ G9: gradients of the reference
+G9_CASES = {   # golden name -> (model name, R, B, detector kwargs) exactly as tests/golden/make_goldens.py::g9_gradients built them
+    "g9_grad_cfg1": ("facebook/dinov2-small", 224, 2, dict(num_classes=91, hidden_dim=256, num_queries=25, num_decoder_layers=2,
+                                                           dim_feedforward=512, lora_r=1, nheads=4, dropout=0.0)),
+    "g9_grad_vitb_224": ("facebook/dinov2-base", 224, 2, dict(num_queries=100, dropout=0.0)),
+}
+
+
+def grad_probe(a):
+    """make_goldens.grad_probe: strided probe (<= 16 x 64) + (sum, abs-sum, L2) of one gradient tensor"""
+    a = np.asarray(a)
+    a2 = a.reshape(a.shape[0], -1) if a.ndim > 1 else a.reshape(1, -1)
+    pr = a2[::max(1, a2.shape[0] // 16), ::max(1, a2.shape[1] // 64)][:16, :64].copy()
+    return pr, np.array([a2.astype(np.float64).sum(), np.abs(a2).astype(np.float64).sum(), np.sqrt((a2.astype(np.float64) ** 2).sum())])
+
+
+def g9_loss_weights(B, Q, C, seed=17):
+    return synth.normal(seed, f"g9.gl.{B}.{Q}.{C}", (B, Q, C), 1.0), synth.normal(seed, f"g9.gb.{B}.{Q}", (B, Q, 4), 1.0)
+
+
+def g9_check(model, g, tol_probe, tol_norm, to_np=lambda t: t.detach().cpu().numpy()):
+    """every gradient the reference's backward() produced (golden g) against `model`'s .grad: the probe entries relative to the
+    probe's max, the whole tensor through its L2 norm and abs-sum; the reference's unreached tensors must be unreached here too.
+    Returns the worst (probe error, name)."""
+    params = dict(model.named_parameters())
+    worst = (0.0, None)
+    for k in g["trainable_with_grad"]:
+        k = str(k)
+        assert k in params and params[k].grad is not None, f"no gradient for {k}"
+        pr, st = grad_probe(to_np(params[k].grad))
+        e = rel_err(pr, g["grad:" + k])
+        worst = max(worst, (e, k))
+        assert e < tol_probe, (k, e)
+        assert abs(st[2] - g["stat:" + k][2]) <= tol_norm * g["stat:" + k][2], (k, st, g["stat:" + k])
+        assert abs(st[1] - g["stat:" + k][1]) <= tol_norm * g["stat:" + k][1], (k, st, g["stat:" + k])
+    for k in g["trainable_without_grad"]:
+        p = params[str(k)]
+        assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+    have = {k for k, p in params.items() if p.grad is not None and float(p.grad.abs().sum()) > 0}
+    assert have == {str(k) for k in g["trainable_with_grad"]}, have ^ {str(k) for k in g["trainable_with_grad"]}
+    return worst

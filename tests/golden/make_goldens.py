@@ -323,8 +323,63 @@ def g8_vitg():
     _e2e("g8_vitg_518", "facebook/dinov2-giant", 518, 1, dict(num_queries=300), block_taps=(0, 19, 39))
 
 
+def grad_probe(a):
+    """what G9 keeps of one gradient tensor: a strided probe (<= 16 x 64 entries) and three checksums of the whole tensor"""
+    a = np.asarray(a)
+    a2 = a.reshape(a.shape[0], -1) if a.ndim > 1 else a.reshape(1, -1)
+    pr = a2[::max(1, a2.shape[0] // 16), ::max(1, a2.shape[1] // 64)][:16, :64].copy()
+    return pr, np.array([a2.astype(np.float64).sum(), np.abs(a2).astype(np.float64).sum(), np.sqrt((a2.astype(np.float64) ** 2).sum())])
+
+
+def g9_loss_weights(B, Q, C, seed=17):
+    """the fixed linear loss of G9: loss = sum(pred_logits * Gl) + sum(pred_boxes * Gb), so d loss / d outputs = (Gl, Gb) exactly"""
+    return synth.normal(seed, f"g9.gl.{B}.{Q}.{C}", (B, Q, C), 1.0), synth.normal(seed, f"g9.gb.{B}.{Q}", (B, Q, 4), 1.0)
+
+
+def g9_gradients():
+    """G9: what `loss.backward()` (train.py:1101) leaves in `.grad` of every trainable parameter of the REFERENCE's
+    DINOv2ObjectDetector in train() mode -- decoder + heads (deformable_attention.py:215-268, tied layers :284), the projection and
+    the LoRA A/B of the last two blocks through the frozen base (dinov2_backbone.py:40-51, utils.py:68-70) -- with dropout = 0 (the
+    five dropout sites are identities: no RNG to reproduce) and a fixed linear loss.  Kept per tensor: a strided probe and checksums
+    of the whole gradient (grad_probe).  cfg1 (ViT-S/14 lightweight, with projection) and ViT-B/14 224x224 with the default 768-wide
+    decoder (the decoder every BASELINE config uses)."""
+    cases_ = [("g9_grad_cfg1", "facebook/dinov2-small", 224, 2,
+               dict(num_classes=91, hidden_dim=256, num_queries=25, num_decoder_layers=2, dim_feedforward=512, lora_r=1, nheads=4, dropout=0.0)),
+              ("g9_grad_vitb_224", "facebook/dinov2-base", 224, 2, dict(num_queries=100, dropout=0.0))]
+    for name, model_name, R, B, kwargs in cases_:
+        hid = kwargs.get("hidden_dim", 768)
+        bb = BackboneConfig.from_name(model_name, lora_r=kwargs.get("lora_r", 2), lora_alpha=1.0, target_dim=hid)
+        _BB_FOR_PATCH["bb"] = bb
+        m = DINOv2ObjectDetector(dino_model_name=model_name, **kwargs)
+        dc = DecoderConfig(num_queries=kwargs.get("num_queries", 50), hidden_dim=hid, nheads=kwargs.get("nheads", 8),
+                           num_layers=kwargs.get("num_decoder_layers", 3), num_classes=kwargs.get("num_classes", 91),
+                           dim_feedforward=kwargs.get("dim_feedforward", 1024), n_points=kwargs.get("n_points", 2), use_deformable=True)
+        _load(m, synth.detector_state_dict(bb, dc, seed=1))
+        m.train()
+        x = torch.from_numpy(synth.make_pixels(B, R, R, seed=0))
+        gl, gb = g9_loss_weights(B, dc.num_queries, dc.num_classes)
+        o = m(x)
+        loss = (o["pred_logits"] * torch.from_numpy(gl)).sum() + (o["pred_boxes"] * torch.from_numpy(gb)).sum()
+        loss.backward()
+        arrs = dict(pred_logits=o["pred_logits"].detach().numpy(), pred_boxes=o["pred_boxes"].detach().numpy(), loss=np.array(float(loss)))
+        names, nograd = [], []
+        for k, p in m.named_parameters():          # tied layers: one name per storage (named_parameters de-duplicates)
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                nograd.append(k)
+                continue
+            pr, st = grad_probe(p.grad.numpy())
+            arrs["grad:" + k], arrs["stat:" + k] = pr, st
+            names.append(k)
+        arrs["trainable_with_grad"] = np.array(names)
+        arrs["trainable_without_grad"] = np.array(nograd)
+        _save(name, **arrs)
+        print(f"{name}: {len(names)} gradients, {len(nograd)} trainable tensors the loss does not reach: {nograd}")
+
+
 CASES = dict(g0=lambda: g0_micro_backbone(False), g4=lambda: g0_micro_backbone(True),
-             g1=g1_decoder_only, g2=g2_cfg1, g3=g3_vitb, g5=g5_postprocess, g6=g6_matcher, g7=g7_vitl, g8=g8_vitg)
+             g1=g1_decoder_only, g2=g2_cfg1, g3=g3_vitb, g5=g5_postprocess, g6=g6_matcher, g7=g7_vitl, g8=g8_vitg, g9=g9_gradients)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -241,10 +241,7 @@ def test_train_step_then_native_eval(G):
     assert rel_err(after[..., 91:].cpu().numpy(), want["pred_boxes"].numpy()) < TOL
     # the composite in eval-equivalent form (no dropout) agrees with the native kernels on the same weights
     m.train()
-    m._dropout_p = m.decoder._dropout_p = 0.0
-    for mod in m.modules():
-        if isinstance(mod, (torch.nn.MultiheadAttention, torch.nn.Dropout)):
-            mod.dropout = 0.0 if isinstance(mod, torch.nn.MultiheadAttention) else mod.p
+    G.no_dropout(m)
     with torch.no_grad():
         comp = m(x)
     assert rel_err(comp["pred_logits"].cpu().numpy(), after[..., :91].cpu().numpy()) < TOL
@@ -257,10 +254,7 @@ def test_train_forward_runs_the_frozen_prefix_natively(G):
     bb, dc = cases.cfg1(25)
     m = G.make_detector(bb, dc, "fp32", "facebook/dinov2-small")
     m.train()
-    m._dropout_p = m.decoder._dropout_p = 0.0
-    for mod in m.modules():
-        if isinstance(mod, torch.nn.MultiheadAttention):
-            mod.dropout = 0.0
+    G.no_dropout(m)
     x = G.to_gpu(synth.make_pixels(2, 224, 224, seed=0))
     eng = m.backbone._get_engine()
     pre = eng.backbone_prefix(x, m.backbone._engine_named(), bb.layers - 2)

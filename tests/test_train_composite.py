@@ -91,3 +91,24 @@ def test_dropout_is_active_in_train_mode_only():
         torch.manual_seed(1)
         b = m(x)["pred_logits"]
     assert not torch.allclose(a, b)
+
+
+@pytest.mark.parametrize("name", sorted(cases.G9_CASES))
+def test_composite_gradients_match_the_reference_backward(name):
+    """G9: the .grad of every trainable parameter after the REFERENCE's own train()-mode forward + backward (dropout 0, fixed linear
+    loss; tests/golden/make_goldens.py::g9_gradients) against the autograd composite's -- the backward of row f1 pinned to what
+    train.py:1101 computes, not to a restatement."""
+    g = cases.golden(name)
+    model_name, R, B, kw = cases.G9_CASES[name]
+    m = DINOv2ObjectDetector(dino_model_name=model_name, pretrained=False, **kw)
+    sd = {k: torch.from_numpy(v) for k, v in synth.detector_state_dict(m._bb_cfg, m._dc_cfg, seed=1).items()}
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    o = m(torch.from_numpy(synth.make_pixels(B, R, R, seed=0)))
+    gl, gb = cases.g9_loss_weights(B, m._dc_cfg.num_queries, m._dc_cfg.num_classes)
+    assert rel_err(o["pred_logits"].detach().numpy(), g["pred_logits"]) < 1e-3
+    loss = (o["pred_logits"] * torch.from_numpy(gl)).sum() + (o["pred_boxes"] * torch.from_numpy(gb)).sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-3 * max(1.0, abs(float(g["loss"])))
+    worst = cases.g9_check(m, g, 2e-4, 2e-4)
+    print(f"{name}: worst gradient probe error {worst[0]:.2e} ({worst[1]})")
