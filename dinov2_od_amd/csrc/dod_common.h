@@ -115,6 +115,7 @@ struct GemmEpi {
   int ksplit;             // ping-pong / H2 kernels only: > 1 = the grid's y index is a K slice of kslice_len k; the slice's fp32 partial
   int kslice_len;         //   product goes to out_f32 + slice * kslice_stride (no other epilogue term may be set)
   long long kslice_stride;
+  int rb;                 // residual epilogue of the 512-thread 256x256 kernels: residual loads in flight per thread (0 = 4; 8, 16)
 };
 
 // ----------------------------------------------------------------------------- launchers (all enqueue on `s`, no sync)

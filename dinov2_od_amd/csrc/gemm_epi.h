@@ -90,6 +90,33 @@ __device__ __forceinline__ ColParams load_col_params(const GemmEpi& e, int n0, i
   return c;
 }
 
+template <int RB, int STEP, int ITER, int C4, typename RowMap>
+__device__ __forceinline__ void drain_resid(const char* sm, int pitch, const GemmEpi& e, const ColParams& cp, int M, int n, int c4, int tid, RowMap rowmap) {
+  const int rb = tid / C4;
+#pragma unroll 1
+  for (int it = 0; it < ITER; it += RB) {
+    float4 r[RB];
+    int mm[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      mm[j] = rowmap(rb + (it + j) * STEP);
+      r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mm[j] < M) r[j] = *reinterpret_cast<const float4*>(e.resid + (size_t)mm[j] * e.ldr + n);
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      if (mm[j] >= M) continue;
+      float4 v = *reinterpret_cast<const float4*>(sm + (rb + (it + j) * STEP) * pitch + c4 * 16);
+      v.x += cp.bias.x; v.y += cp.bias.y; v.z += cp.bias.z; v.w += cp.bias.w;
+      if (e.act == ACT_GELU) { v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w); }
+      else if (e.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      v.x = fmaf(v.x, cp.scale.x, r[j].x); v.y = fmaf(v.y, cp.scale.y, r[j].y);
+      v.z = fmaf(v.z, cp.scale.z, r[j].z); v.w = fmaf(v.w, cp.scale.w, r[j].w);
+      *reinterpret_cast<float4*>(e.out_f32 + (size_t)mm[j] * e.ldc + n) = v;
+    }
+  }
+}
+
 // rows of the LDS tile map to global rows through `rowmap` (row_l -> m)
 template <int ROWS, int COLS, int NT, typename RowMap>
 __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const GemmEpi& e, const ColParams& cp, int M, int N,
@@ -103,32 +130,12 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
     // The in-place fp32 residual epilogue (out-proj, fc2): a thread visits ROWS / (NT / C4) rows, and with one residual load in flight
     // per thread the pass is a chain of memory latencies (tools/pp_timeline.py: 63 k cycles per 256x256 tile, 15 GB/s per CU).
     // Rows go in batches of RB: RB residual loads are issued before the first of them is consumed.  (Unrolling the whole generic loop
-    // instead makes the 256x256 kernels spill: QKV 1345 vs 808 us.)
-    constexpr int STEP = NT / C4, ITER = ROWS / STEP, RB = ITER % 4 == 0 ? 4 : (ITER % 2 == 0 ? 2 : 1);   // 8 in flight: the 1024-thread kernels (128 VGPRs) slow down (out-proj 235 vs 204 us)
+    // instead makes the 256x256 kernels spill: QKV 1345 vs 808 us.)  RB = 4 by default; 8 in flight slow the 1024-thread kernels down
+    // (128 VGPRs: out-proj 235 vs 204 us); the 512-thread kernels (256 VGPRs) take a deeper batch through e.rb (round 3).
+    constexpr int STEP = NT / C4, ITER = ROWS / STEP;
     static_assert(ROWS % STEP == 0, "whole passes over the tile rows");
-    const int rb = tid / C4;
-#pragma unroll 1
-    for (int it = 0; it < ITER; it += RB) {
-      float4 r[RB];
-      int mm[RB];
-#pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        mm[j] = rowmap(rb + (it + j) * STEP);
-        r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mm[j] < M) r[j] = *reinterpret_cast<const float4*>(e.resid + (size_t)mm[j] * e.ldr + n);
-      }
-#pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        if (mm[j] >= M) continue;
-        float4 v = *reinterpret_cast<const float4*>(sm + (rb + (it + j) * STEP) * pitch + c4 * 16);
-        v.x += cp.bias.x; v.y += cp.bias.y; v.z += cp.bias.z; v.w += cp.bias.w;
-        if (e.act == ACT_GELU) { v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w); }
-        else if (e.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        v.x = fmaf(v.x, cp.scale.x, r[j].x); v.y = fmaf(v.y, cp.scale.y, r[j].y);
-        v.z = fmaf(v.z, cp.scale.z, r[j].z); v.w = fmaf(v.w, cp.scale.w, r[j].w);
-        *reinterpret_cast<float4*>(e.out_f32 + (size_t)mm[j] * e.ldc + n) = v;
-      }
-    }
+    if (NT <= 512 && ITER % 8 == 0 && e.rb == 8) { drain_resid<8, STEP, ITER, C4>(sm, pitch, e, cp, M, n, c4, tid, rowmap); return; }
+    drain_resid<(ITER % 4 == 0 ? 4 : (ITER % 2 == 0 ? 2 : 1)), STEP, ITER, C4>(sm, pitch, e, cp, M, n, c4, tid, rowmap);
     return;
   }
 #pragma unroll

@@ -761,6 +761,13 @@ int launch_gemm_bf16_pp(const bf16_t* A, int lda, const bf16_t* W, int ldw, int 
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
+// residual loads in flight per thread in the in-place residual epilogue of the 512-thread kernels (gemm_epi.h drain_resid):
+// DINODET_EPI_RB = 4 | 8 | 16 (read per launch: A/B in one process)
+static int epi_rb() {
+  const char* v = getenv("DINODET_EPI_RB");
+  return v ? atoi(v) : 0;
+}
+
 static void ppm_attr() {
   static bool attr_set[16] = {};
   int dev = 0;
@@ -784,8 +791,10 @@ int launch_gemm_bf16_ppm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int
   const int gm = gemm_tile_mode();
   const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
   const char* f_ = getenv("DINODET_GEMM_TILE");
-  if (f_ && f_[0] == 'r') hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, true>), dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
-  else hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, false>), dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
+  GemmEpi e2 = e;
+  if (!e2.rb) e2.rb = epi_rb();
+  if (f_ && f_[0] == 'r') hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, true>), dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e2, gm);
+  else hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, false>), dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e2, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -797,6 +806,7 @@ int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int 
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
   GemmEpi e2 = e;
+  if (!e2.rb) e2.rb = epi_rb();
   if (getenv("DINODET_DEBUG_NOOUT")) { e2.ldc = 0; e2.ldr = 0; }   // tuning only: every output row aliases row 0
   ppm_attr();
   if (getenv("DINODET_DEBUG_LDA0")) lda = 0;      // tuning only: every A row aliases row 0 (A traffic becomes cache hits)
@@ -828,7 +838,9 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
   const int gm = gemm_tile_mode();
   const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
   if (const char* v = getenv("DINODET_DEBUG_LDA0")) lda = atoi(v) & ~15;   // tuning only: A row pitch override (0: every row aliases row 0; 64: 16-row pieces contiguous)
-  hipLaunchKernelGGL(gemm_h2_256x256_kernel, dim3(tiles), dim3(512), LDSH2, s, (const char*)A, lda, (const char*)W, ldw, M, N, K, e, gm);
+  GemmEpi e2 = e;
+  if (!e2.rb) e2.rb = epi_rb();
+  hipLaunchKernelGGL(gemm_h2_256x256_kernel, dim3(tiles), dim3(512), LDSH2, s, (const char*)A, lda, (const char*)W, ldw, M, N, K, e2, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

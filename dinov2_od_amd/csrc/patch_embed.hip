@@ -35,11 +35,15 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const void* __restrict
   const int wm = wu >> 1, wn = wu & 1;
   const int Np = gh * gw, Mtot = B * Np;
   const int tiles_m = (Mtot + PE_M - 1) / PE_M;
-  // consecutive blocks share a patch tile (all n-tiles of it run together: the pixels are fetched from HBM once, the whole packed
-  // weight -- 1 MB at D = 768 -- stays in L2 anyway)
+  // XCD-aware order (round 3): workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own L2.  All n-tiles of a
+  // patch tile are given to ONE XCD, back to back in its dispatch order -- the pixels are then fetched from HBM once and hit that
+  // XCD's L2 for the other tiles_n - 1 readers; the packed weight (1 MB at D = 768) stays in every L2 anyway.  With consecutive
+  // blocks sharing a patch tile (rounds 1-2) its six n-tiles sat on six XCDs: 1 796 MB of HBM-side traffic per batch of 64
+  // against 475 MB algorithmic (profiles/r02_pmc_traffic_bf16.json).
   const int tiles_n = (D + PE_N - 1) / PE_N;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
-  (void)tiles_m;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int tn = idx % tiles_n, tm = (idx / tiles_n) * 8 + xcd;
+  if (tm >= tiles_m) return;                            // the grid is padded to whole groups of 8 patch tiles
   const int m0 = tm * PE_M, n0 = tn * PE_N;
   const int nsteps = 3 * (p / 2), kp = nsteps * 32;
 
@@ -229,7 +233,7 @@ int launch_patch_embed(const void* img, int u8, int B, int H, int W, int p, cons
   if (gh <= 0 || gw <= 0) return 2;
   if ((size_t)B * 3 * H * W >= 0xffffffffull) return 2;          // 32-bit element offsets
   const int kp = 3 * (p / 2) * 32, ldw = x3 ? 2 * kp : kp;
-  const int tiles = (((B * gh * gw) + PE_M - 1) / PE_M) * ((D + PE_N - 1) / PE_N);
+  const int tiles = ((((B * gh * gw) + PE_M - 1) / PE_M + 7) / 8 * 8) * ((D + PE_N - 1) / PE_N);     // patch tiles padded to groups of 8 (one per XCD)
   const int lds = 2 * (x3 ? 4 : 2) * PE_PLANE;
 #define PE_LAUNCH(X3_, U8_, P_) hipLaunchKernelGGL((patch_embed_kernel<X3_, U8_, P_>), dim3(tiles), dim3(256), lds, s, img, Wp, ldw, bias, pos, out, B, H, W, gh, gw, D)
   if (p == 14) {

@@ -15,6 +15,10 @@ from dinov2_od_amd import _native as nat
 
 def set_variant(v):
     os.environ.pop("DINODET_GEMM_STAGGER", None)
+    os.environ.pop("DINODET_EPI_RB", None)
+    if "#" in v:                               # "<tile>#<rb>": residual loads in flight per thread (512-thread kernels)
+        v, rb = v.split("#")
+        os.environ["DINODET_EPI_RB"] = rb
     if "@" in v:                               # "<tile>@<groups>,<step_us>": start stagger
         v, st = v.split("@")
         os.environ["DINODET_GEMM_STAGGER"] = st
