@@ -45,6 +45,19 @@ class DodDecTrainParams(C.Structure):
     _fields_ = [(f, C.c_void_p) for f in DEC_TRAIN_FIELDS]
 
 
+DENSE_LAYER_FIELDS = ["sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ca_in_w", "ca_in_b", "ca_out_w", "ca_out_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
+                      "norm1_w", "norm1_b", "norm2_w", "norm2_b", "norm3_w", "norm3_b"]
+
+
+class DodDenseLayerParams(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in DENSE_LAYER_FIELDS]
+
+
+class DodDenseDecTrainParams(C.Structure):
+    _fields_ = [("nlayers", C.c_int32), ("reserved", C.c_int32), ("layers", C.POINTER(DodDenseLayerParams))] + \
+               [(f, C.c_void_p) for f in ("query_embed", "class_w", "class_b", "bb0_w", "bb0_b", "bb2_w", "bb2_b")]
+
+
 class DodLoraLinear(C.Structure):
     _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("A", C.c_void_p), ("Bm", C.c_void_p)]
 
@@ -104,6 +117,10 @@ SYMBOLS = {
     "dod_decoder_train_forward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _F, C.c_uint64, _P, _P, _SZ, _P, _SZ, _P]),
     "dod_decoder_train_backward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _F, C.c_uint64, _P, _P, _SZ, _P, _P, _P, _SZ, _P]),
     "dod_decoder_train_last_error": (C.c_char_p, []),
+    "dod_dense_decoder_train_tape_bytes": (_SZ, [C.POINTER(DodConfig), _I, _I]),
+    "dod_dense_decoder_train_workspace_bytes": (_SZ, [C.POINTER(DodConfig), _I, _I]),
+    "dod_dense_decoder_train_forward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _F, C.c_uint64, _P, _P, _SZ, _P, _SZ, _P]),
+    "dod_dense_decoder_train_backward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _F, C.c_uint64, _P, _P, _SZ, _P, _P, _P, _SZ, _P]),
     "dod_backbone_tail_tape_bytes": (_SZ, [C.POINTER(DodConfig), _I, _I, _I]),
     "dod_backbone_tail_workspace_bytes": (_SZ, [C.POINTER(DodConfig), _I, _I, _I]),
     "dod_backbone_tail_train_forward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _P, _P, _SZ, _P, _SZ, _P]),

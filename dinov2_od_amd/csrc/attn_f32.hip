@@ -119,13 +119,13 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32 a) {
   }
 }
 
-int launch_attn_f32_mfma(const AttnF32& a, hipStream_t s);   // attn_f32m.hip: head_dim 64 on the fp32 MFMA
+int launch_attn_f32_mfma(const AttnF32& a, hipStream_t s);   // attn_f32m.hip: head_dim 32 / 64 / 96 on the fp32 MFMA
 
 int launch_attn_f32(const AttnF32& a, hipStream_t s) {
   if (a.B <= 0 || a.heads <= 0 || a.Lq <= 0 || a.Lk <= 0) return 1;
   {
     static const char* fm = getenv("DINODET_ATTN_F32_MFMA");     // "0": always the generic VALU kernel (A/B)
-    if ((!fm || fm[0] != '0') && a.dh == 64 && a.ldo % 4 == 0 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0)
+    if ((!fm || fm[0] != '0') && (a.dh == 32 || a.dh == 64 || a.dh == 96) && a.ldo % 4 == 0 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0)
       return launch_attn_f32_mfma(a, s);
   }
   if (a.dh % 4 != 0 || a.dh > 128 || a.dh <= 0) return 2;

@@ -148,11 +148,11 @@ __global__ void batch_sum_kernel(const float* __restrict__ d, float* __restrict_
 // ------------------------------------------------------------------------------------------------ LayerNorm backward
 // x: the pre-norm input (t = residual + branch), dy: gradient of the LayerNorm output.  dx per row; dgamma / dbeta accumulated
 // per wave over its rows, then one float atomic per column and wave.
+template <int MAXC>       // 64-column chunks per lane: 16 (D <= 1024) or 32 (D <= 2048: ViT-g's 1536)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dy,
                                                      float eps, int rows, int D, float* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta) {
   const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-  constexpr int MAXC = 16;                         // D <= 1024
   float dg[MAXC], db[MAXC];
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) { dg[c] = 0.f; db[c] = 0.f; }
@@ -197,9 +197,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   }
 }
 int ln_bwd(const float* x, const float* gamma, const float* dy, float eps, int rows, int D, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
-  if (D > 1024) return 2;
+  if (D > 2048) return 2;
   int blocks = (rows + 3) / 4; blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);      // one row per wave up to 8 192 rows
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, gamma, dy, eps, rows, D, dx, dgamma, dbeta);
+  if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, x, gamma, dy, eps, rows, D, dx, dgamma, dbeta);
+  else hipLaunchKernelGGL(ln_bwd_kernel<32>, dim3(blocks), dim3(256), 0, s, x, gamma, dy, eps, rows, D, dx, dgamma, dbeta);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -296,65 +297,86 @@ GemmF32X mha_gemm(const float* A, int lda, long long a_sb, long long a_sh, bool 
 // (DINODET_MHA_CHUNK_MB) instead of growing with the batch (1 370 tokens x 12 heads: 90 MB per image per buffer).  Passes small
 // enough to keep the scores in the 256 MB Infinity Cache between launches were measured and do not pay: ViT-B 518x518, batch 8,
 // one image per pass 23.0 ms per step, two 22.0, the whole batch in one pass 21.7.
-inline int mha_chunk_images(int B, int Hd, int Q) {
+inline int mha_chunk_images(int B, int Hd, int Lq, int Lk) {
   const char* ei = getenv("DINODET_MHA_CHUNK_IMAGES");          // tests: force several (ragged) passes on small shapes
   if (ei && atoi(ei) > 0) return atoi(ei) > B ? B : atoi(ei);
   const char* e = getenv("DINODET_MHA_CHUNK_MB");
   const size_t mb = e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)1024;
-  const size_t per = (size_t)Hd * Q * up4((size_t)Q) * 4;
+  const size_t per = (size_t)Hd * Lq * up4((size_t)Lk) * 4;
   size_t c = (mb << 20) / (per ? per : 1);
   if (c < 1) c = 1;
   return c > (size_t)B ? B : (int)c;
 }
-inline size_t mha_scratch_floats(int B, int Hd, int Q) { return (size_t)mha_chunk_images(B, Hd, Q) * Hd * Q * up4((size_t)Q); }
+inline int mha_chunk_images(int B, int Hd, int Q) { return mha_chunk_images(B, Hd, Q, Q); }
+inline size_t mha_scratch_floats(int B, int Hd, int Lq, int Lk) { return (size_t)mha_chunk_images(B, Hd, Lq, Lk) * Hd * Lq * up4((size_t)Lk); }
+inline size_t mha_scratch_floats(int B, int Hd, int Q) { return mha_scratch_floats(B, Hd, Q, Q); }
 
-// S: mha_scratch_floats() of scratch
-static int launch_mha_fwd_train(const float* qkv, int ld, float* out, int ldo, float* S, int B, int Q, int Hd, int Dd, int dh, float scale, float p,
-                                unsigned long long key, hipStream_t s) {
-  const int Qp = (int)up4((size_t)Q);
-  const long long qs = (long long)Q * ld, ss = (long long)Q * Qp;
-  const int cb = mha_chunk_images(B, Hd, Q);
+// General (rectangular) form: queries q [B*Lq, ldq], keys / values k, v [B*Lk, ldkv] (head h at columns h*dh of each), Lk <= MHA_MAXQ.
+// The decoder's self-attention passes q | k | v of one packed buffer (Lq = Lk = Q); the dense cross-attention of the
+// nn.TransformerDecoder branch (detr_decoder.py:28-35) passes Lq = Q queries against the Lk = N memory tokens.
+// S: mha_scratch_floats(B, Hd, Lq, Lk) of scratch
+static int launch_mha_fwd_rect(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo, float* S, int B, int Lq, int Lk,
+                               int Hd, int dh, float scale, float p, unsigned long long key, hipStream_t s) {
+  if (Lk > MHA_MAXQ) return 2;
+  const int Lkp = (int)up4((size_t)Lk);
+  const long long qs = (long long)Lq * ldq, ks = (long long)Lk * ldkv, ss = (long long)Lq * Lkp;
+  const int cb = mha_chunk_images(B, Hd, Lq, Lk);
   for (int b0 = 0; b0 < B; b0 += cb) {
     const int nb = B - b0 < cb ? B - b0 : cb;
-    const float* q0 = qkv + (size_t)b0 * qs;
-    int rc = launch_gemm_f32x(mha_gemm(q0, ld, qs, dh, false, q0 + Dd, ld, qs, dh, false, S, Qp, ss * Hd, ss, Q, Q, dh, nb, Hd, scale), s);
+    const float* q0 = q + (size_t)b0 * qs;
+    const float* k0 = k + (size_t)b0 * ks;
+    const float* v0 = v + (size_t)b0 * ks;
+    int rc = launch_gemm_f32x(mha_gemm(q0, ldq, qs, dh, false, k0, ldkv, ks, dh, false, S, Lkp, ss * Hd, ss, Lq, Lk, dh, nb, Hd, scale), s);
     if (rc) return rc;
-    const long nrows = (long)nb * Hd * Q;
-    hipLaunchKernelGGL(mha_softmax_fwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, S, Q, Qp, nrows, (long)b0 * Hd * Q, p, key);
+    const long nrows = (long)nb * Hd * Lq;
+    hipLaunchKernelGGL(mha_softmax_fwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, S, Lk, Lkp, nrows, (long)b0 * Hd * Lq, p, key);
     if (hipGetLastError() != hipSuccess) return 3;
-    rc = launch_gemm_f32x(mha_gemm(S, Qp, ss * Hd, ss, false, q0 + 2 * Dd, ld, qs, dh, true, out + (size_t)b0 * Q * ldo, ldo, (long long)Q * ldo, dh, Q, dh, Q,
+    rc = launch_gemm_f32x(mha_gemm(S, Lkp, ss * Hd, ss, false, v0, ldkv, ks, dh, true, out + (size_t)b0 * Lq * ldo, ldo, (long long)Lq * ldo, dh, Lq, dh, Lk,
                                    nb, Hd, 1.0f), s);
     if (rc) return rc;
   }
   return 0;
 }
-// dS, Pd: mha_scratch_floats() of scratch each
-static int launch_mha_bwd(const float* qkv, int ld, const float* dO, int ldo, float* dqkv, float* dS, float* Pd, int B, int Q, int Hd, int Dd,
-                          int dh, float scale, float p, unsigned long long key, hipStream_t s) {
-  const int Qp = (int)up4((size_t)Q);
-  const long long qs = (long long)Q * ld, os = (long long)Q * ldo, ss = (long long)Q * Qp;
-  const int cb = mha_chunk_images(B, Hd, Q);
+// dS, Pd: mha_scratch_floats(B, Hd, Lq, Lk) of scratch each; dq [B*Lq, lddq], dk, dv [B*Lk, lddkv] are WRITTEN (not accumulated)
+static int launch_mha_bwd_rect(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* dO, int ldo, float* dq, int lddq, float* dk,
+                               float* dv, int lddkv, float* dS, float* Pd, int B, int Lq, int Lk, int Hd, int dh, float scale, float p,
+                               unsigned long long key, hipStream_t s) {
+  if (Lk > MHA_MAXQ) return 2;
+  const int Lkp = (int)up4((size_t)Lk);
+  const long long qs = (long long)Lq * ldq, ks = (long long)Lk * ldkv, os = (long long)Lq * ldo, ss = (long long)Lq * Lkp;
+  const long long dqs = (long long)Lq * lddq, dks = (long long)Lk * lddkv;
+  const int cb = mha_chunk_images(B, Hd, Lq, Lk);
   for (int b0 = 0; b0 < B; b0 += cb) {
     const int nb = B - b0 < cb ? B - b0 : cb;
-    const float* q0 = qkv + (size_t)b0 * qs;
+    const float* q0 = q + (size_t)b0 * qs;
+    const float* k0 = k + (size_t)b0 * ks;
+    const float* v0 = v + (size_t)b0 * ks;
     const float* o0 = dO + (size_t)b0 * os;
-    float* g0 = dqkv + (size_t)b0 * qs;
-    int rc = launch_gemm_f32x(mha_gemm(q0, ld, qs, dh, false, q0 + Dd, ld, qs, dh, false, Pd, Qp, ss * Hd, ss, Q, Q, dh, nb, Hd, scale), s);
+    int rc = launch_gemm_f32x(mha_gemm(q0, ldq, qs, dh, false, k0, ldkv, ks, dh, false, Pd, Lkp, ss * Hd, ss, Lq, Lk, dh, nb, Hd, scale), s);
     if (rc) return rc;
-    rc = launch_gemm_f32x(mha_gemm(o0, ldo, os, dh, false, q0 + 2 * Dd, ld, qs, dh, false, dS, Qp, ss * Hd, ss, Q, Q, dh, nb, Hd, 1.0f), s);
+    rc = launch_gemm_f32x(mha_gemm(o0, ldo, os, dh, false, v0, ldkv, ks, dh, false, dS, Lkp, ss * Hd, ss, Lq, Lk, dh, nb, Hd, 1.0f), s);
     if (rc) return rc;
-    const long nrows = (long)nb * Hd * Q;
-    hipLaunchKernelGGL(mha_softmax_bwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, Pd, dS, Q, Qp, nrows, (long)b0 * Hd * Q, p, key);
+    const long nrows = (long)nb * Hd * Lq;
+    hipLaunchKernelGGL(mha_softmax_bwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, Pd, dS, Lk, Lkp, nrows, (long)b0 * Hd * Lq, p, key);
     if (hipGetLastError() != hipSuccess) return 3;
     // dq = scale dS k;  dk = scale dS^T q;  dv = Pd^T dO      (k, q, dO enter as the k-major operand: [token, dh] views)
-    rc = launch_gemm_f32x(mha_gemm(dS, Qp, ss * Hd, ss, false, q0 + Dd, ld, qs, dh, true, g0, ld, qs, dh, Q, dh, Q, nb, Hd, scale), s);
+    rc = launch_gemm_f32x(mha_gemm(dS, Lkp, ss * Hd, ss, false, k0, ldkv, ks, dh, true, dq + (size_t)b0 * dqs, lddq, dqs, dh, Lq, dh, Lk, nb, Hd, scale), s);
     if (rc) return rc;
-    rc = launch_gemm_f32x(mha_gemm(dS, Qp, ss * Hd, ss, true, q0, ld, qs, dh, true, g0 + Dd, ld, qs, dh, Q, dh, Q, nb, Hd, scale), s);
+    rc = launch_gemm_f32x(mha_gemm(dS, Lkp, ss * Hd, ss, true, q0, ldq, qs, dh, true, dk + (size_t)b0 * dks, lddkv, dks, dh, Lk, dh, Lq, nb, Hd, scale), s);
     if (rc) return rc;
-    rc = launch_gemm_f32x(mha_gemm(Pd, Qp, ss * Hd, ss, true, o0, ldo, os, dh, true, g0 + 2 * Dd, ld, qs, dh, Q, dh, Q, nb, Hd, 1.0f), s);
+    rc = launch_gemm_f32x(mha_gemm(Pd, Lkp, ss * Hd, ss, true, o0, ldo, os, dh, true, dv + (size_t)b0 * dks, lddkv, dks, dh, Lk, dh, Lq, nb, Hd, 1.0f), s);
     if (rc) return rc;
   }
   return 0;
+}
+// the packed self-attention forms: qkv [B*Q, ld] = [q | k | v]
+static int launch_mha_fwd_train(const float* qkv, int ld, float* out, int ldo, float* S, int B, int Q, int Hd, int Dd, int dh, float scale, float p,
+                                unsigned long long key, hipStream_t s) {
+  return launch_mha_fwd_rect(qkv, ld, qkv + Dd, qkv + 2 * Dd, ld, out, ldo, S, B, Q, Q, Hd, dh, scale, p, key, s);
+}
+static int launch_mha_bwd(const float* qkv, int ld, const float* dO, int ldo, float* dqkv, float* dS, float* Pd, int B, int Q, int Hd, int Dd,
+                          int dh, float scale, float p, unsigned long long key, hipStream_t s) {
+  return launch_mha_bwd_rect(qkv, ld, qkv + Dd, qkv + 2 * Dd, ld, dO, ldo, dqkv, ld, dqkv + Dd, dqkv + 2 * Dd, ld, dS, Pd, B, Q, Q, Hd, dh, scale, p, key, s);
 }
 
 // ------------------------------------------------------------------------------------------------ deformable gather backward
@@ -726,6 +748,203 @@ int dod_decoder_train_backward(const dod_config* cfg, const dod_dec_train_params
 }  // extern "C"
 
 // =============================================================================================================================
+// Dense decoder: the nn.TransformerDecoder branch (detr_decoder.py:28-35, 62-69; torch's TransformerDecoderLayer, post-norm, ReLU):
+//   x  = LN1(x + drop1(MHA(x, x, x)))              self-attention over the Q queries (probabilities dropped inside the MHA)
+//   x  = LN2(x + drop2(MHA(x, memory, memory)))    dense cross-attention: Q queries x N memory tokens per head
+//   x  = LN3(x + drop3(lin2(drop(relu(lin1(x))))))
+// layers untied; heads as in the deformable branch.  Dropout sites per layer: 0 self-attn probabilities, 1 dropout1, 2 dropout2,
+// 3 the FFN's inner dropout, 4 dropout3, 5 cross-attn probabilities.
+namespace {
+
+struct DDims { int B, N, Q, Dd, Hd, F, C, L, dh, BQ, M; };
+bool make_ddims(const dod_config* c, int B, int N, DDims* d) {
+  if (!c || B <= 0 || N <= 0 || c->use_deformable) return false;
+  d->B = B; d->N = N; d->Q = c->num_queries; d->Dd = c->dec_hidden; d->Hd = c->dec_heads; d->F = c->dim_feedforward; d->C = c->num_classes;
+  d->L = c->dec_layers; d->dh = d->Dd / d->Hd; d->BQ = B * d->Q; d->M = B * N;
+  if (d->Dd % d->Hd || d->dh > 128 || d->dh % 4 || d->Dd % 4 || d->F % 4 || (d->Dd / 2) % 4 || d->Dd > 1024 || d->Q > MHA_MAXQ || N > MHA_MAXQ || d->L < 1 || d->L > 16)
+    return false;
+  return true;
+}
+struct DTape {
+  float *hs, *hb, *boxes;
+  struct Layer { float *x_in, *qkv, *att, *t1, *x1, *cq, *ckv, *catt, *t2, *x2, *hid, *t3; } l[16];
+};
+size_t carve_dtape(const DDims& d, void* base, DTape* t) {
+  size_t off = 0;
+  auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr; off += al256(n * 4); return p; };
+  const size_t BQ = d.BQ, Dd = d.Dd;
+  DTape tt;
+  tt.hs = take(BQ * Dd); tt.hb = take(BQ * (Dd / 2)); tt.boxes = take(BQ * 4);
+  for (int j = 0; j < d.L; ++j) {
+    auto& L = tt.l[j];
+    L.x_in = take(BQ * Dd); L.qkv = take(BQ * 3 * Dd); L.att = take(BQ * Dd); L.t1 = take(BQ * Dd); L.x1 = take(BQ * Dd);
+    L.cq = take(BQ * Dd); L.ckv = take((size_t)d.M * 2 * Dd); L.catt = take(BQ * Dd); L.t2 = take(BQ * Dd); L.x2 = take(BQ * Dd);
+    L.hid = take(BQ * (size_t)d.F); L.t3 = take(BQ * Dd);
+  }
+  if (t) *t = tt;
+  return off;
+}
+struct DScratch { float *y, *dx, *dt, *dbr, *dbig, *dqkv, *dcq, *dckv, *dS, *Pd, *dhb, *dz, *dmem; };
+size_t carve_dscratch(const DDims& d, void* base, DScratch* sc) {
+  size_t off = 0;
+  auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr; off += al256(n * 4); return p; };
+  const size_t BQ = d.BQ, Dd = d.Dd, F = d.F;
+  const size_t maxcols = (size_t)(3 * Dd > F ? 3 * Dd : F);
+  const size_t sq = mha_scratch_floats(d.B, d.Hd, d.Q, d.Q), sr = mha_scratch_floats(d.B, d.Hd, d.Q, d.N);
+  DScratch s;
+  s.y = take(BQ * maxcols); s.dx = take(BQ * Dd); s.dt = take(BQ * Dd); s.dbr = take(BQ * Dd); s.dbig = take(BQ * maxcols);
+  s.dqkv = take(BQ * 3 * Dd); s.dcq = take(BQ * Dd); s.dckv = take((size_t)d.M * 2 * Dd);
+  s.dS = take(sq > sr ? sq : sr); s.Pd = take(sq > sr ? sq : sr); s.dhb = take(BQ * (Dd / 2)); s.dz = take(BQ * 4);
+  s.dmem = take((size_t)d.M * Dd);
+  if (sc) *sc = s;
+  return off;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dod_dense_decoder_train_tape_bytes(const dod_config* cfg, int B, int N) {
+  DDims d; if (!make_ddims(cfg, B, N, &d)) return 0;
+  return carve_dtape(d, nullptr, nullptr) + 256;
+}
+size_t dod_dense_decoder_train_workspace_bytes(const dod_config* cfg, int B, int N) {
+  DDims d; if (!make_ddims(cfg, B, N, &d)) return 0;
+  return carve_dscratch(d, nullptr, nullptr) + 256;
+}
+
+int dod_dense_decoder_train_forward(const dod_config* cfg, const dod_dense_dec_train_params* p, const float* memory, int B, int N, float dropout_p,
+                                    uint64_t seed, float* det, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
+  DDims d;
+  if (!make_ddims(cfg, B, N, &d)) return tfail(DOD_ERR_INVALID, "dense decoder train: unsupported configuration (nn.TransformerDecoder branch, head_dim <= 128, Dd <= 1024, Q and N <= %d, <= 16 layers)", MHA_MAXQ);
+  if (!p || !p->layers || p->nlayers != d.L || !memory || !det || !tape || !ws) return tfail(DOD_ERR_INVALID, "dense decoder train: null buffer / layer count mismatch");
+  if (dropout_p < 0.f || dropout_p >= 1.f) return tfail(DOD_ERR_INVALID, "dense decoder train: dropout %g outside [0, 1)", dropout_p);
+  if (tape_bytes < dod_dense_decoder_train_tape_bytes(cfg, B, N) || ws_bytes < dod_dense_decoder_train_workspace_bytes(cfg, B, N))
+    return tfail(DOD_ERR_STATE, "dense decoder train: tape / workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  DTape t; DScratch sc;
+  carve_dtape(d, (void*)(((uintptr_t)tape + 255) & ~(uintptr_t)255), &t);
+  carve_dscratch(d, (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &sc);
+  const int BQ = d.BQ, Dd = d.Dd, Q = d.Q, F = d.F;
+  const float scale = 1.0f / sqrtf((float)d.dh);
+  const size_t nBD = (size_t)BQ * Dd;
+  TK(launch_bcast_rows(p->query_embed, t.l[0].x_in, B, Q, Dd, s));
+  for (int j = 0; j < d.L; ++j) {
+    const dod_dense_layer_params& W = p->layers[j];
+    auto& L = t.l[j];
+    // self-attention block
+    TK(lin_fwd(L.x_in, Dd, W.sa_in_w, W.sa_in_b, BQ, 3 * Dd, Dd, L.qkv, 3 * Dd, ACT_NONE, s));
+    TK(launch_mha_fwd_train(L.qkv, 3 * Dd, L.att, Dd, sc.Pd, B, Q, d.Hd, Dd, d.dh, scale, dropout_p, site_key(seed, j, 0), s));
+    TK(lin_fwd(L.att, Dd, W.sa_out_w, W.sa_out_b, BQ, Dd, Dd, sc.y, Dd, ACT_NONE, s));
+    TK(dropout_add(L.x_in, sc.y, L.t1, nBD, dropout_p, site_key(seed, j, 1), s));
+    TK(launch_layernorm(L.t1, nullptr, W.norm1_w, W.norm1_b, cfg->dec_ln_eps, BQ, Dd, L.x1, nullptr, s));
+    // dense cross-attention: q from the queries, k | v from the memory (in_proj rows 0..Dd-1 / Dd..3Dd-1)
+    TK(lin_fwd(L.x1, Dd, W.ca_in_w, W.ca_in_b, BQ, Dd, Dd, L.cq, Dd, ACT_NONE, s));
+    TK(lin_fwd(memory, Dd, W.ca_in_w + (size_t)Dd * Dd, W.ca_in_b + Dd, d.M, 2 * Dd, Dd, L.ckv, 2 * Dd, ACT_NONE, s));
+    TK(launch_mha_fwd_rect(L.cq, Dd, L.ckv, L.ckv + Dd, 2 * Dd, L.catt, Dd, sc.Pd, B, Q, N, d.Hd, d.dh, scale, dropout_p, site_key(seed, j, 5), s));
+    TK(lin_fwd(L.catt, Dd, W.ca_out_w, W.ca_out_b, BQ, Dd, Dd, sc.y, Dd, ACT_NONE, s));
+    TK(dropout_add(L.x1, sc.y, L.t2, nBD, dropout_p, site_key(seed, j, 2), s));
+    TK(launch_layernorm(L.t2, nullptr, W.norm2_w, W.norm2_b, cfg->dec_ln_eps, BQ, Dd, L.x2, nullptr, s));
+    // FFN
+    TK(lin_fwd(L.x2, Dd, W.lin1_w, W.lin1_b, BQ, F, Dd, L.hid, F, ACT_RELU, s));                         // taped: post-ReLU, pre-dropout
+    const float* hin = L.hid;
+    if (dropout_p > 0.f) { TK(dropout_add(nullptr, L.hid, sc.y, (size_t)BQ * F, dropout_p, site_key(seed, j, 3), s)); hin = sc.y; }
+    TK(lin_fwd(hin, F, W.lin2_w, W.lin2_b, BQ, Dd, F, sc.dbig, Dd, ACT_NONE, s));
+    TK(dropout_add(L.x2, sc.dbig, L.t3, nBD, dropout_p, site_key(seed, j, 4), s));
+    float* nxt = j + 1 < d.L ? t.l[j + 1].x_in : t.hs;
+    TK(launch_layernorm(L.t3, nullptr, W.norm3_w, W.norm3_b, cfg->dec_ln_eps, BQ, Dd, nxt, nullptr, s));
+  }
+  const int C = d.C;
+  TK(launch_gemm_f32(t.hs, Dd, p->class_w, Dd, BQ, C, Dd, gepi(p->class_b, det, C + 4), s));
+  TK(lin_fwd(t.hs, Dd, p->bb0_w, p->bb0_b, BQ, Dd / 2, Dd, t.hb, Dd / 2, ACT_RELU, s));
+  TK(launch_gemm_f32(t.hb, Dd / 2, p->bb2_w, Dd / 2, BQ, 4, Dd / 2, gepi(p->bb2_b, det + C, C + 4, ACT_SIGMOID), s));
+  TK(launch_copy2d(det + C, C + 4, t.boxes, 4, BQ, 4, 4, s));
+  return DOD_OK;
+}
+
+int dod_dense_decoder_train_backward(const dod_config* cfg, const dod_dense_dec_train_params* p, const float* memory, int B, int N, float dropout_p,
+                                     uint64_t seed, const float* d_det, const void* tape, size_t tape_bytes, const dod_dense_dec_train_params* grads,
+                                     float* d_memory, void* ws, size_t ws_bytes, void* stream) {
+  DDims d;
+  if (!make_ddims(cfg, B, N, &d)) return tfail(DOD_ERR_INVALID, "dense decoder train: unsupported configuration");
+  if (!p || !p->layers || p->nlayers != d.L || !grads || !grads->layers || grads->nlayers != d.L || !memory || !d_det || !tape || !ws)
+    return tfail(DOD_ERR_INVALID, "dense decoder train: null buffer / layer count mismatch");
+  if (tape_bytes < dod_dense_decoder_train_tape_bytes(cfg, B, N) || ws_bytes < dod_dense_decoder_train_workspace_bytes(cfg, B, N))
+    return tfail(DOD_ERR_STATE, "dense decoder train: tape / workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  DTape t; DScratch sc;
+  carve_dtape(d, (void*)(((uintptr_t)tape + 255) & ~(uintptr_t)255), &t);
+  carve_dscratch(d, (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), &sc);
+  auto G = [](const float* q) { return const_cast<float*>(q); };
+  const int BQ = d.BQ, Dd = d.Dd, Q = d.Q, C = d.C, F = d.F;
+  const float scale = 1.0f / sqrtf((float)d.dh);
+  const size_t nBD = (size_t)BQ * Dd;
+  float* dmem = d_memory ? d_memory : sc.dmem;                 // d(memory): the sum over the layers' k | v projections
+  TH(hipMemsetAsync(dmem, 0, (size_t)d.M * Dd * 4, s));
+  // ---- heads (detr_decoder.py:80-81; utils.py:14-30)
+  hipLaunchKernelGGL(sigmoid_bwd4_kernel, dim3((BQ * 4 + 255) / 256), dim3(256), 0, s, d_det + C, C + 4, t.boxes, 4, sc.dz, BQ);
+  TH(hipGetLastError());
+  TK(lin_bwd_w(sc.dz, 4, t.hb, Dd / 2, BQ, 4, Dd / 2, G(grads->bb2_w), G(grads->bb2_b), s));
+  TK(lin_bwd_x(sc.dz, 4, p->bb2_w, BQ, 4, Dd / 2, sc.dhb, false, s));
+  {
+    const size_t n = (size_t)BQ * (Dd / 2);
+    hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, sc.dhb, t.hb, sc.dhb, n, 0.f, 0ull);
+    TH(hipGetLastError());
+  }
+  TK(lin_bwd_w(sc.dhb, Dd / 2, t.hs, Dd, BQ, Dd / 2, Dd, G(grads->bb0_w), G(grads->bb0_b), s));
+  TK(lin_bwd_x(sc.dhb, Dd / 2, p->bb0_w, BQ, Dd / 2, Dd, sc.dx, false, s));
+  TK(lin_bwd_w(d_det, C + 4, t.hs, Dd, BQ, C, Dd, G(grads->class_w), G(grads->class_b), s));
+  TK(lin_bwd_x(d_det, C + 4, p->class_w, BQ, C, Dd, sc.dx, true, s));                                   // dx = d(layer output)
+  for (int j = d.L - 1; j >= 0; --j) {
+    const dod_dense_layer_params& W = p->layers[j];
+    const dod_dense_layer_params& Gw = grads->layers[j];
+    const auto& L = t.l[j];
+    // LN3 <- x2 + drop3(lin2(drop(relu(lin1(x2)))))
+    TK(ln_bwd(L.t3, W.norm3_w, sc.dx, cfg->dec_ln_eps, BQ, Dd, sc.dt, G(Gw.norm3_w), G(Gw.norm3_b), s));           // dt = d(t3)
+    TK(dropout_add(nullptr, sc.dt, sc.dbr, nBD, dropout_p, site_key(seed, j, 4), s));                              // d(lin2 output)
+    const float* hin = L.hid;
+    if (dropout_p > 0.f) { TK(dropout_add(nullptr, L.hid, sc.y, (size_t)BQ * F, dropout_p, site_key(seed, j, 3), s)); hin = sc.y; }
+    TK(lin_bwd_w(sc.dbr, Dd, hin, F, BQ, Dd, F, G(Gw.lin2_w), G(Gw.lin2_b), s));
+    TK(lin_bwd_x(sc.dbr, Dd, W.lin2_w, BQ, Dd, F, sc.dbig, false, s));
+    {
+      const size_t n = (size_t)BQ * F;
+      hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, sc.dbig, L.hid, sc.dbig, n,
+                         dropout_p, site_key(seed, j, 3));
+      TH(hipGetLastError());
+    }
+    TK(lin_bwd_w(sc.dbig, F, L.x2, Dd, BQ, F, Dd, G(Gw.lin1_w), G(Gw.lin1_b), s));
+    TK(lin_bwd_x(sc.dbig, F, W.lin1_w, BQ, F, Dd, sc.dt, true, s));                                               // dt = d(x2): residual + FFN input
+    // LN2 <- x1 + drop2(ca_out(catt))
+    TK(ln_bwd(L.t2, W.norm2_w, sc.dt, cfg->dec_ln_eps, BQ, Dd, sc.dx, G(Gw.norm2_w), G(Gw.norm2_b), s));           // dx = d(t2)
+    TK(dropout_add(nullptr, sc.dx, sc.dbr, nBD, dropout_p, site_key(seed, j, 2), s));
+    TK(lin_bwd_w(sc.dbr, Dd, L.catt, Dd, BQ, Dd, Dd, G(Gw.ca_out_w), G(Gw.ca_out_b), s));
+    TK(lin_bwd_x(sc.dbr, Dd, W.ca_out_w, BQ, Dd, Dd, sc.dt, false, s));                                            // dt = d(catt)
+    TK(launch_mha_bwd_rect(L.cq, Dd, L.ckv, L.ckv + Dd, 2 * Dd, sc.dt, Dd, sc.dcq, Dd, sc.dckv, sc.dckv + Dd, 2 * Dd, sc.dS, sc.Pd, B, Q, N, d.Hd, d.dh,
+                           scale, dropout_p, site_key(seed, j, 5), s));
+    // in_proj of the cross-attention: rows 0..Dd-1 see the queries, rows Dd..3Dd-1 the memory
+    TK(lin_bwd_w(sc.dcq, Dd, L.x1, Dd, BQ, Dd, Dd, G(Gw.ca_in_w), G(Gw.ca_in_b), s));
+    TK(lin_bwd_w(sc.dckv, 2 * Dd, memory, Dd, d.M, 2 * Dd, Dd, G(Gw.ca_in_w) + (size_t)Dd * Dd, G(Gw.ca_in_b) + Dd, s));
+    TK(lin_bwd_x(sc.dckv, 2 * Dd, W.ca_in_w + (size_t)Dd * Dd, d.M, 2 * Dd, Dd, dmem, true, s));                   // d(memory) += d(k | v) W_kv
+    TK(lin_bwd_x(sc.dcq, Dd, W.ca_in_w, BQ, Dd, Dd, sc.dx, true, s));                                              // dx = d(x1): residual + query input
+    // LN1 <- x_in + drop1(sa_out(att))
+    TK(ln_bwd(L.t1, W.norm1_w, sc.dx, cfg->dec_ln_eps, BQ, Dd, sc.dt, G(Gw.norm1_w), G(Gw.norm1_b), s));           // dt = d(t1)
+    TK(dropout_add(nullptr, sc.dt, sc.dbr, nBD, dropout_p, site_key(seed, j, 1), s));
+    TK(lin_bwd_w(sc.dbr, Dd, L.att, Dd, BQ, Dd, Dd, G(Gw.sa_out_w), G(Gw.sa_out_b), s));
+    TK(lin_bwd_x(sc.dbr, Dd, W.sa_out_w, BQ, Dd, Dd, sc.dx, false, s));                                            // dx = d(att)
+    TK(launch_mha_bwd(L.qkv, 3 * Dd, sc.dx, Dd, sc.dqkv, sc.dS, sc.Pd, B, Q, d.Hd, Dd, d.dh, scale, dropout_p, site_key(seed, j, 0), s));
+    TK(lin_bwd_w(sc.dqkv, 3 * Dd, L.x_in, Dd, BQ, 3 * Dd, Dd, G(Gw.sa_in_w), G(Gw.sa_in_b), s));
+    TK(lin_bwd_x(sc.dqkv, 3 * Dd, W.sa_in_w, BQ, 3 * Dd, Dd, sc.dt, true, s));                                     // dt = d(x_in): the layer below's d(output)
+    TH(hipMemcpyAsync(sc.dx, sc.dt, nBD * 4, hipMemcpyDeviceToDevice, s));
+  }
+  // query embedding: x_0[b] = query_embed for every image (detr_decoder.py:59)
+  hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)(((size_t)Q * Dd + 255) / 256)), dim3(256), 0, s, sc.dx, G(grads->query_embed), B, (size_t)Q * Dd);
+  TH(hipGetLastError());
+  return DOD_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================================================
 // Backbone tail: the LoRA-adapted encoder blocks (dinov2_backbone.py:45-51: the last two), the final LayerNorm and the projection
 // (dinov2_backbone.py:33-37, 64-65) in train() mode -- the rest of what `loss.backward()` (train.py:1101) reaches: gradients of every
 // lora_A / lora_B (utils.py:46-70) and of the projection.  The DINOv2 weights, LayerNorms, LayerScales and biases are frozen
@@ -744,7 +963,7 @@ bool make_tdims(const dod_config* c, int B, int N, int nblocks, TDims* d) {
   d->B = B; d->N = N; d->M = B * N; d->D = c->hidden; d->H = c->heads; d->dh = d->D / d->H; d->F = c->ffn_hidden;
   d->swiglu = c->swiglu ? 1 : 0; d->F1 = c->swiglu ? 2 * c->ffn_hidden : c->ffn_hidden;
   d->Dd = c->target_dim ? c->target_dim : c->hidden; d->nb = nblocks; d->r = c->lora_r; d->alpha = c->lora_alpha; d->eps = c->ln_eps;
-  if (d->D % d->H || d->dh > 128 || d->dh % 4 || d->D % 4 || d->F % 4 || d->D > 1024 * 16 || N > MHA_MAXQ || d->r < 1 || d->r > 64) return false;
+  if (d->D % d->H || d->dh > 128 || d->dh % 4 || d->D % 4 || d->F % 4 || d->D > 2048 || N > MHA_MAXQ || d->r < 1 || d->r > 64) return false;   // D: ln_bwd / launch_layernorm
   return true;
 }
 struct TTape {

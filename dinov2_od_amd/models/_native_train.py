@@ -116,6 +116,117 @@ def decoder_train(m, src, seed=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
+# dense decoder: the nn.TransformerDecoder branch (use_deformable=False; dod_dense_decoder_train_forward / _backward)
+def _dense_layer_tensors(L):
+    """the 18 tensors of struct dod_dense_layer_params, in its order (torch.nn.TransformerDecoderLayer)"""
+    return [L.self_attn.in_proj_weight, L.self_attn.in_proj_bias, L.self_attn.out_proj.weight, L.self_attn.out_proj.bias,
+            L.multihead_attn.in_proj_weight, L.multihead_attn.in_proj_bias, L.multihead_attn.out_proj.weight, L.multihead_attn.out_proj.bias,
+            L.linear1.weight, L.linear1.bias, L.linear2.weight, L.linear2.bias,
+            L.norm1.weight, L.norm1.bias, L.norm2.weight, L.norm2.bias, L.norm3.weight, L.norm3.bias]
+
+
+def _dense_param_list(m):
+    out = []
+    for L in m.decoder.layers:
+        out += _dense_layer_tensors(L)
+    return out + [m.query_embed.weight, m.class_embed.weight, m.class_embed.bias,
+                  m.bbox_embed.mlp[0].weight, m.bbox_embed.mlp[0].bias, m.bbox_embed.mlp[2].weight, m.bbox_embed.mlp[2].bias]
+
+
+def dense_dropout_rate(m):
+    """the one rate of torch's six dropout sites per layer (both attentions' probabilities, dropout1/2/3, the FFN's dropout), each
+    0 when its module is in eval(); None when they disagree (then the composite runs)"""
+    rates = set()
+    for L in m.decoder.layers:
+        for d in (L.dropout, L.dropout1, L.dropout2, L.dropout3):
+            rates.add(float(d.p) if d.training else 0.0)
+        for a in (L.self_attn, L.multihead_attn):
+            rates.add(float(a.dropout) if a.training else 0.0)
+    return rates.pop() if len(rates) == 1 else None
+
+
+def dense_supported(m, src):
+    """the reference's standard branch as torch builds it: post-norm ReLU layers, no final norm, fp32 CUDA tensors, shapes the native
+    side takes (dod_dense_decoder_train_tape_bytes > 0)"""
+    if m.use_deformable or not (src.is_cuda and src.dtype == torch.float32 and src.dim() == 3):
+        return False
+    if getattr(m.decoder, "norm", None) is not None:
+        return False
+    for L in m.decoder.layers:
+        if getattr(L, "norm_first", False) or getattr(L.self_attn, "batch_first", False):
+            return False
+        act = getattr(L, "activation", None)
+        if not (act is torch.nn.functional.relu or isinstance(act, torch.nn.ReLU)):
+            return False
+        if L.self_attn.in_proj_weight is None or L.multihead_attn.in_proj_weight is None:
+            return False
+    if not all(p.is_cuda and p.dtype == torch.float32 for p in _dense_param_list(m)) or dense_dropout_rate(m) is None:
+        return False
+    cfg = make_config(m._bb_cfg, m._dc_cfg, "fp32")
+    return nat.lib().dod_dense_decoder_train_tape_bytes(C.byref(cfg), int(src.shape[0]), int(src.shape[1])) > 0
+
+
+def _dense_struct(tensors, nlayers):
+    layers = (nat.DodDenseLayerParams * nlayers)()
+    it = iter(tensors)
+    for lp in layers:
+        for f in nat.DENSE_LAYER_FIELDS:
+            setattr(lp, f, next(it).data_ptr())
+    ps = nat.DodDenseDecTrainParams()
+    ps.nlayers, ps.layers = nlayers, layers
+    for f in ("query_embed", "class_w", "class_b", "bb0_w", "bb0_b", "bb2_w", "bb2_b"):
+        setattr(ps, f, next(it).data_ptr())
+    return ps, layers          # keep `layers` alive as long as `ps`
+
+
+class _DenseDecoderTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, cfg, p, seed, *params):
+        L = nat.lib()
+        B, N, _ = src.shape
+        src = src.contiguous()
+        params = [t.detach().contiguous() for t in params]
+        nl = cfg.dec_layers
+        with torch.cuda.device(src.device):
+            tape = torch.empty(L.dod_dense_decoder_train_tape_bytes(C.byref(cfg), B, N), dtype=torch.uint8, device=src.device)
+            ws = torch.empty(L.dod_dense_decoder_train_workspace_bytes(C.byref(cfg), B, N), dtype=torch.uint8, device=src.device)
+            if tape.numel() == 0 or ws.numel() == 0:
+                raise ValueError("decoder configuration not supported by the native training kernels")
+            det = torch.empty(B, cfg.num_queries, cfg.num_classes + 4, dtype=torch.float32, device=src.device)
+            ps, keep = _dense_struct(params, nl)
+            _check(L.dod_dense_decoder_train_forward(C.byref(cfg), C.byref(ps), nat.ptr(src), B, N, float(p), int(seed), nat.ptr(det), nat.ptr(tape),
+                                                     tape.numel(), nat.ptr(ws), ws.numel(), nat.stream_ptr()))
+        ctx.save_for_backward(src, tape, *params)
+        ctx.cfg, ctx.p, ctx.seed, ctx.ws = cfg, float(p), int(seed), ws
+        return det
+
+    @staticmethod
+    def backward(ctx, d_det):
+        L = nat.lib()
+        src, tape, *params = ctx.saved_tensors
+        cfg = ctx.cfg
+        B, N, _ = src.shape
+        d_det = d_det.contiguous().float()
+        with torch.cuda.device(src.device):
+            grads = [torch.zeros_like(t) for t in params]
+            d_src = torch.empty_like(src)
+            ps, k1 = _dense_struct(params, cfg.dec_layers)
+            gs, k2 = _dense_struct(grads, cfg.dec_layers)
+            _check(L.dod_dense_decoder_train_backward(C.byref(cfg), C.byref(ps), nat.ptr(src), B, N, ctx.p, ctx.seed, nat.ptr(d_det), nat.ptr(tape),
+                                                      tape.numel(), C.byref(gs), nat.ptr(d_src), nat.ptr(ctx.ws), ctx.ws.numel(), nat.stream_ptr()))
+        return (d_src, None, None, None, *grads)
+
+
+def dense_decoder_train(m, src, seed=None):
+    """DETRDecoder.forward (use_deformable=False) in train() mode -> packed detections [B, Q, C+4] with the autograd edge to the native backward"""
+    cfg = make_config(m._bb_cfg, m._dc_cfg, "fp32")
+    if seed is None:
+        _seed_counter[0] += 1
+        seed = (int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) << 20) ^ _seed_counter[0]
+    return _DenseDecoderTrain.apply(src, cfg, dense_dropout_rate(m), seed, *_dense_param_list(m))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
 # backbone tail: the LoRA-adapted blocks + final LayerNorm + projection (dod_backbone_tail_train_forward / _backward)
 _LORA_SITES = ("q", "k", "v", "o", "fc1", "fc2")
 

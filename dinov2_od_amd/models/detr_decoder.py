@@ -106,10 +106,14 @@ class DETRDecoder(_EngineMixin, nn.Module):
         if self._use_autograd(src):
             import os
             from . import _autograd, _native_train
-            # train(): decoder + heads on the native kernels with their hand-written backward (deformable branch, the reference's
-            # default); the dense nn.TransformerDecoder branch and CPU tensors (test suite only) stay on the autograd composite
-            if os.environ.get("DINODET_NATIVE_TRAIN", "1") != "0" and _native_train.supported(self, src):
-                return split_detections(_native_train.decoder_train(self, src), self._dc_cfg.num_classes)
+            # train(): decoder + heads on the native kernels with their hand-written backward -- the deformable branch (the reference's
+            # default) and, round 3, the dense nn.TransformerDecoder branch; CPU tensors (test suite only) and shapes the kernels do not
+            # take stay on the autograd composite
+            if os.environ.get("DINODET_NATIVE_TRAIN", "1") != "0":
+                if _native_train.supported(self, src):
+                    return split_detections(_native_train.decoder_train(self, src), self._dc_cfg.num_classes)
+                if _native_train.dense_supported(self, src):
+                    return split_detections(_native_train.dense_decoder_train(self, src), self._dc_cfg.num_classes)
             return _autograd.decoder_forward(self, src)
         det = self._get_engine().decoder_forward(src, self._engine_named())
         return split_detections(det, self._dc_cfg.num_classes)

@@ -287,12 +287,39 @@ int dod_decoder_train_backward(const dod_config* cfg, const dod_dec_train_params
                                void* stream);
 const char* dod_decoder_train_last_error(void);
 
+/* The nn.TransformerDecoder branch of DETRDecoder (use_deformable = False; detr_decoder.py:28-35, 62-69) in train() mode:
+ * post-norm nn.TransformerDecoderLayer x L with UNTIED weights -- query self-attention, dense cross-attention of the Q queries over
+ * all N memory tokens, ReLU FFN, three LayerNorms, dropout at torch's six sites (both attentions' probabilities, dropout1/2/3 and
+ * the FFN's inner dropout) -- and the same heads.  Same contract as dod_decoder_train_*: `grads` has the layout of the parameters
+ * (float accumulators), `layers` is a HOST array of nlayers entries holding device pointers. */
+typedef struct dod_dense_layer_params {
+  const float *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b;      /* self_attn: in_proj [3Dd, Dd], out_proj [Dd, Dd] */
+  const float *ca_in_w, *ca_in_b, *ca_out_w, *ca_out_b;      /* multihead_attn: in_proj [3Dd, Dd] = q (queries) | k | v (memory) */
+  const float *lin1_w, *lin1_b, *lin2_w, *lin2_b;            /* [F, Dd], [Dd, F] */
+  const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b;
+} dod_dense_layer_params;
+typedef struct dod_dense_dec_train_params {
+  int32_t nlayers, reserved;
+  const dod_dense_layer_params* layers;
+  const float *query_embed, *class_w, *class_b, *bb0_w, *bb0_b, *bb2_w, *bb2_b;
+} dod_dense_dec_train_params;
+size_t dod_dense_decoder_train_tape_bytes(const dod_config* cfg, int B, int N);
+size_t dod_dense_decoder_train_workspace_bytes(const dod_config* cfg, int B, int N);
+int dod_dense_decoder_train_forward(const dod_config* cfg, const dod_dense_dec_train_params* params, const float* memory, int B, int N,
+                                    float dropout_p, uint64_t seed, float* detections, void* tape, size_t tape_bytes,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+int dod_dense_decoder_train_backward(const dod_config* cfg, const dod_dense_dec_train_params* params, const float* memory, int B, int N,
+                                     float dropout_p, uint64_t seed, const float* d_detections, const void* tape, size_t tape_bytes,
+                                     const dod_dense_dec_train_params* grads, float* d_memory, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+
 /* The rest of the trainable subset: the LoRA-adapted encoder blocks (the last two, dinov2_backbone.py:45-51), the final
  * LayerNorm and the projection (dinov2_backbone.py:33-37, 64-65) in train() mode.  x_in [B, N, D] is the residual stream in
  * front of the first adapted block (dod_backbone_prefix: everything before it is frozen and needs no autograd); the forward
  * writes the decoder memory [B, N, Dd] and tapes its activations, the backward turns d(memory) into the gradients of every
  * lora_A / lora_B (dino_detector/utils.py:46-70) and of the projection.  Frozen tensors (w, b, LayerNorm, LayerScale) are read
- * only; in `grads` only A, Bm, proj_w, proj_b are written (float accumulators, same layout).  GELU-MLP variants (ViT-S/B/L);
+ * only; in `grads` only A, Bm, proj_w, proj_b are written (float accumulators, same layout).  GELU MLP (ViT-S/B/L) or SwiGLU
+ * (ViT-g, cfg->swiglu: the fc1 / fc2 slots then hold mlp.weights_in [2F, D] / mlp.weights_out [D, F]); hidden <= 2048;
  * errors through dod_decoder_train_last_error(). */
 typedef struct dod_lora_linear { const float *w, *b, *A, *Bm; } dod_lora_linear;        /* [out,in], [out], [r,in], [out,r] */
 typedef struct dod_bb_block_params {

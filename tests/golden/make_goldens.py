@@ -345,7 +345,11 @@ def g9_gradients():
     decoder (the decoder every BASELINE config uses)."""
     cases_ = [("g9_grad_cfg1", "facebook/dinov2-small", 224, 2,
                dict(num_classes=91, hidden_dim=256, num_queries=25, num_decoder_layers=2, dim_feedforward=512, lora_r=1, nheads=4, dropout=0.0)),
-              ("g9_grad_vitb_224", "facebook/dinov2-base", 224, 2, dict(num_queries=100, dropout=0.0))]
+              ("g9_grad_vitb_224", "facebook/dinov2-base", 224, 2, dict(num_queries=100, dropout=0.0)),
+              # the nn.TransformerDecoder branch (detr_decoder.py:28-35, 62-69): untied layers, dense cross-attention over all tokens
+              ("g9_grad_cfg1_dense", "facebook/dinov2-small", 224, 2,
+               dict(num_classes=91, hidden_dim=256, num_queries=25, num_decoder_layers=2, dim_feedforward=512, lora_r=1, nheads=4, dropout=0.0,
+                    use_deformable=False))]
     for name, model_name, R, B, kwargs in cases_:
         hid = kwargs.get("hidden_dim", 768)
         bb = BackboneConfig.from_name(model_name, lora_r=kwargs.get("lora_r", 2), lora_alpha=1.0, target_dim=hid)
@@ -353,7 +357,8 @@ def g9_gradients():
         m = DINOv2ObjectDetector(dino_model_name=model_name, **kwargs)
         dc = DecoderConfig(num_queries=kwargs.get("num_queries", 50), hidden_dim=hid, nheads=kwargs.get("nheads", 8),
                            num_layers=kwargs.get("num_decoder_layers", 3), num_classes=kwargs.get("num_classes", 91),
-                           dim_feedforward=kwargs.get("dim_feedforward", 1024), n_points=kwargs.get("n_points", 2), use_deformable=True)
+                           dim_feedforward=kwargs.get("dim_feedforward", 1024), n_points=kwargs.get("n_points", 2),
+                           use_deformable=kwargs.get("use_deformable", True))
         _load(m, synth.detector_state_dict(bb, dc, seed=1))
         m.train()
         x = torch.from_numpy(synth.make_pixels(B, R, R, seed=0))
