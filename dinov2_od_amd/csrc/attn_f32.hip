@@ -125,11 +125,12 @@ int launch_attn_f32(const AttnF32& a, hipStream_t s) {
   if (a.B <= 0 || a.heads <= 0 || a.Lq <= 0 || a.Lk <= 0) return 1;
   {
     static const char* fm = getenv("DINODET_ATTN_F32_MFMA");     // "0": always the generic VALU kernel (A/B)
-    if ((!fm || fm[0] != '0') && (a.dh == 32 || a.dh == 64 || a.dh == 96) && a.ldo % 4 == 0 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0)
+    if ((a.lse || !fm || fm[0] != '0') && (a.dh == 32 || a.dh == 64 || a.dh == 96) && a.ldo % 4 == 0 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0)
       return launch_attn_f32_mfma(a, s);
   }
   if (a.dh % 4 != 0 || a.dh > 128 || a.dh <= 0) return 2;
   if (a.ldq % 4 || a.ldk % 4 || a.ldv % 4) return 2;
+  if (a.lse) return 2;                       // the log-sum-exp output exists in the MFMA kernel only
   const size_t lds = sizeof(float) * ((size_t)AF_KV * (a.dh + 4) + (size_t)AF_KV * a.dh +
                                       (size_t)AF_WAVES * AF_R * a.dh + (size_t)AF_WAVES * AF_R * AF_KV);
   static bool attr_set = false;

@@ -968,7 +968,7 @@ bool make_tdims(const dod_config* c, int B, int N, int nblocks, TDims* d) {
 }
 struct TTape {
   float* xout; float* f;
-  struct Blk { float *x, *y1, *qkv, *ctx, *x1, *y2, *pre, *h, *Wqkv, *Wo, *W1, *W2, *bqkv; } b[8];
+  struct Blk { float *x, *y1, *qkv, *ctx, *x1, *y2, *pre, *h, *Wqkv, *Wo, *W1, *W2, *bqkv, *lse; } b[8];
 };
 size_t carve_ttape(const TDims& d, void* base, TTape* t) {
   size_t off = 0;
@@ -981,18 +981,27 @@ size_t carve_ttape(const TDims& d, void* base, TTape* t) {
     b.x = take(M * D); b.y1 = take(M * D); b.qkv = take(M * 3 * D); b.ctx = take(M * D); b.x1 = take(M * D); b.y2 = take(M * D);
     b.pre = take(M * (size_t)d.F1); b.h = take(M * F);
     b.Wqkv = take(3 * D * D); b.Wo = take(D * D); b.W1 = take((size_t)d.F1 * D); b.W2 = take(D * F); b.bqkv = take(3 * D);
+    b.lse = take(M * (size_t)d.H);                 // log-sum-exp of every score row [B, H, N]: the flash-style attention adjoint
   }
   if (t) *t = tt;
   return off;
 }
-struct TScratch { float *dx, *da, *db, *dbig, *dqkv, *dS, *Pd, *T, *U, *dump, *dh; };
+struct TScratch { float *dx, *da, *db, *dbig, *dqkv, *dS, *Pd, *T, *U, *dump, *dh, *delta; };
+// head_dim 64 (every DINOv2 variant): the attention adjoint recomputes its scores tile by tile (attn_f32m.hip launch_attn_f32_bwd) -- no
+// [B*H, N, N] score / adjoint scratch.  DINODET_ATTN_BWD_FLASH=0 keeps the batched-GEMM form (A/B, and the form other head sizes take).
+inline bool tail_flash_bwd(const TDims& d) {
+  static const char* e = getenv("DINODET_ATTN_BWD_FLASH");
+  return d.dh == 64 && !(e && e[0] == '0');
+}
 size_t carve_tscratch(const TDims& d, void* base, TScratch* sc) {
   size_t off = 0;
   auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr; off += al256(n * 4); return p; };
   const size_t M = d.M, D = d.D, F = d.F1, big = F > 3 * D ? F : 3 * D;
   TScratch s;
   s.dx = take(M * D); s.da = take(M * D); s.db = take(M * D); s.dbig = take(M * big); s.dqkv = take(M * 3 * D);
-  s.dS = take(mha_scratch_floats(d.B, d.H, d.N)); s.Pd = take(mha_scratch_floats(d.B, d.H, d.N));
+  const bool flash = tail_flash_bwd(d);
+  s.dS = take(flash ? 0 : mha_scratch_floats(d.B, d.H, d.N)); s.Pd = take(flash ? 0 : mha_scratch_floats(d.B, d.H, d.N));
+  s.delta = take(M * (size_t)d.H);
   s.T = take(M * up4(d.r)); s.U = take(M * up4(d.r)); s.dump = take(2 * big);
   s.dh = d.swiglu ? take(M * (size_t)d.F) : nullptr;        // SwiGLU: d(h) [M, F] beside d(pre) [M, 2F] (the tape stays read-only)
   if (sc) *sc = s;
@@ -1127,6 +1136,7 @@ int dod_backbone_tail_train_forward(const dod_config* cfg, const dod_bb_tail_par
     {
       AttnF32 a; a.q = tb.qkv; a.k = tb.qkv + D; a.v = tb.qkv + 2 * D; a.o = tb.ctx; a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
       a.Lq = a.Lk = N; a.B = B; a.heads = d.H; a.dh = d.dh; a.scale = scale;
+      if (d.dh == 64) a.lse = tb.lse;            // fp32-MFMA flash kernel: the adjoint's log-sum-exp comes for free
       TK(launch_attn_f32(a, s));
     }
     {   // x1 = x + ls1 * (ctx Wo'^T + bo)
@@ -1208,7 +1218,16 @@ int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_pa
     TH(hipGetLastError());
     TK(lora_grads(d, tb.ctx, D, sc.da, D, D, bp.o.A, bp.o.Bm, G(gp.o.A), G(gp.o.Bm), sc, s));
     TK(lin_bwd_x(sc.da, D, tb.Wo, M, D, D, sc.db, false, s));                                                         // db = d(ctx)
-    TK(launch_mha_bwd(tb.qkv, 3 * D, sc.db, D, sc.dqkv, sc.dS, sc.Pd, B, N, d.H, D, d.dh, scale, 0.f, 0ull, s));
+    if (tail_flash_bwd(d)) {
+      AttnF32Bwd g;
+      g.q = tb.qkv; g.k = tb.qkv + D; g.v = tb.qkv + 2 * D; g.o = tb.ctx; g.d_o = sc.db; g.lse = tb.lse;
+      g.dq = sc.dqkv; g.dk = sc.dqkv + D; g.dv = sc.dqkv + 2 * D; g.delta = sc.delta;
+      g.ldq = g.ldk = g.ldv = g.lddq = g.lddk = g.lddv = 3 * D; g.ldo = D;
+      g.Lq = g.Lk = N; g.B = B; g.heads = d.H; g.dh = d.dh; g.scale = scale;
+      TK(launch_attn_f32_bwd(g, s));
+    } else {
+      TK(launch_mha_bwd(tb.qkv, 3 * D, sc.db, D, sc.dqkv, sc.dS, sc.Pd, B, N, d.H, D, d.dh, scale, 0.f, 0ull, s));
+    }
     const dod_lora_linear* qkv3[3] = {&bp.q, &bp.k, &bp.v};
     const dod_lora_linear* gqkv3[3] = {&gp.q, &gp.k, &gp.v};
     for (int c = 0; c < 3; ++c)

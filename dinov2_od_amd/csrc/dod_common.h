@@ -171,8 +171,21 @@ struct AttnF32 {
   int Lq, Lk;                 // rows per batch item
   int B, heads, dh;
   float scale;
+  float* lse = nullptr;       // optional [B, heads, Lq]: log2-domain log-sum-exp of every score row, max_j(s c) + log2(sum_j 2^(s c - max)),
+                              // c = scale log2(e) -- what the flash-style adjoint (launch_attn_f32_bwd) needs; MFMA kernel only
 };
 int launch_attn_f32(const AttnF32& a, hipStream_t s);
+// Adjoint of launch_attn_f32 without materialised scores (attn_f32m.hip; head_dim 64, exact-fp32 MFMA): q | k | v and their gradients
+// as strided [rows, ld] views like the forward's, o / d_o [B*Lq, ldo], lse from the forward, delta [B, heads, Lq] scratch.
+// Returns 2 when the shape is not taken (the caller keeps its batched-GEMM adjoint).
+struct AttnF32Bwd {
+  const float *q, *k, *v, *o, *d_o, *lse;
+  float *dq, *dk, *dv, *delta;
+  int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+  int Lq, Lk, B, heads, dh;
+  float scale;
+};
+int launch_attn_f32_bwd(const AttnF32Bwd& a, hipStream_t s);
 
 // patch im2col: img [B,3,H,W] fp32 -> A [B*gh*gw, Kp] (k = c*p*p + i*p + j, zero padded to Kp)
 int launch_im2col(const float* img, int B, int H, int W, int patch, int Kp, float* out_f32, bf16_t* out_bf16, hipStream_t s);
