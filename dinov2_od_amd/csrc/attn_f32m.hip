@@ -125,7 +125,10 @@ __global__ __launch_bounds__(256, 2) void attn_f32m_kernel(AttnF32 a) {
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   const int q = q0 + lr;
-  if (a.lse && active && q < a.Lq && lh == 0) a.lse[((size_t)b * a.heads + h) * a.Lq + q] = m_run + log2f(l_tot);
+  // (max, sum) of the row in the log2 domain, kept SEPARATE: folded into one log-sum-exp float (magnitude ~20, ulp 2e-6) the adjoint's
+  // recomputed probabilities carry a 1e-6 relative error per row -- measured as 3-5x the gradient error of the batched-GEMM adjoint
+  if (a.lse && active && q < a.Lq && lh == 0)
+    *reinterpret_cast<float2*>(a.lse + (((size_t)b * a.heads + h) * a.Lq + q) * 2) = make_float2(m_run, l_tot);
   if (active && q < a.Lq) {
     float* op = a.o + ((size_t)b * a.Lq + q) * a.ldo + h * DH;
 #pragma unroll
@@ -153,7 +156,7 @@ int launch_attn_f32_mfma(const AttnF32& a, hipStream_t s) {
 // Flash-style adjoint (head_dim 64): the training step's backbone-tail attention backward (dec_train.hip) without the [B*H, N, N]
 // score / probability / adjoint buffers of the batched-GEMM form (~6 GB of traffic per ViT-B block at 8 x 1 370 tokens).  Scores are
 // recomputed tile by tile from q, k and the forward's log-sum-exp; every product on the exact-fp32 MFMA:
-//   P = 2^(s c - L_q),  dP = dO V^T,  dS = P o (dP - delta_q),  delta_q = <dO_q, O_q>
+//   P = 2^(s c - m_q) / l_q  (the forward's row max and sum),  dP = dO V^T,  dS = P o (dP - delta_q),  delta_q = <dO_q, O_q>
 //   dV = P^T dO,  dK = scale dS^T Q                 (attn_f32m_bwd_kv: a wave owns 32 KEYS on the MFMA lane, loops over query tiles)
 //   dQ = scale dS K                                 (attn_f32m_bwd_q : a wave owns 32 QUERIES on the MFMA lane, loops over key tiles)
 // Operand layouts follow the forward: the tile being looped over sits TRANSPOSED in LDS ([d][row], pitch 97) -- read with consecutive
@@ -202,7 +205,7 @@ __device__ __forceinline__ void fb_stage_t(float* dst, const float* src, int ld,
 __global__ __launch_bounds__(256, 2) void attn_f32m_bwd_kv_kernel(AttnF32Bwd a) {
   __shared__ float sQt[64 * FM_LDK];      // [d][query]
   __shared__ float sOt[64 * FM_LDK];      // dO, [d][query]
-  __shared__ float sL[FB_T], sD[FB_T];
+  __shared__ float sL[FB_T], sI[FB_T], sD[FB_T];        // row max, 1 / row sum, delta
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32m_bwd_kv_kernel(AttnF32Bwd a) 
   const float* K = a.k + (size_t)b * a.Lk * a.ldk + h * 64;
   const float* V = a.v + (size_t)b * a.Lk * a.ldv + h * 64;
   const float* DO = a.d_o + (size_t)b * a.Lq * a.ldo + h * 64;
-  const float* LSE = a.lse + ((size_t)b * a.heads + h) * a.Lq;
+  const float* LSE = a.lse + ((size_t)b * a.heads + h) * a.Lq * 2;
   const float* DEL = a.delta + ((size_t)b * a.heads + h) * a.Lq;
   float kf[32], vf[32];                   // B operands of k-step st (d = 2 st + lh) for key lr
   {
@@ -235,7 +238,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32m_bwd_kv_kernel(AttnF32Bwd a) 
     fb_stage_t(sOt, DO, a.ldo, qt * FB_T, a.Lq, tid, true);         // rows beyond Lq: dO = 0 (and L = +inf below: P = 0)
     if (tid < FB_T) {
       const int q = qt * FB_T + tid;
-      sL[tid] = q < a.Lq ? LSE[q] : INFINITY;
+      sL[tid] = q < a.Lq ? LSE[2 * q] : INFINITY;         // rows beyond Lq: 2^(-inf) = 0
+      sI[tid] = q < a.Lq ? 1.0f / LSE[2 * q + 1] : 0.f;
       sD[tid] = q < a.Lq ? DEL[q] : 0.f;
     }
     __syncthreads();
@@ -258,11 +262,12 @@ __global__ __launch_bounds__(256, 2) void attn_f32m_bwd_kv_kernel(AttnF32Bwd a) 
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 L4 = *reinterpret_cast<const float4*>(sL + qb * 32 + 8 * g + 4 * lh);
+        const float4 I4 = *reinterpret_cast<const float4*>(sI + qb * 32 + 8 * g + 4 * lh);
         const float4 D4 = *reinterpret_cast<const float4*>(sD + qb * 32 + 8 * g + 4 * lh);
-        const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv[4] = {D4.x, D4.y, D4.z, D4.w};
+        const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Iv[4] = {I4.x, I4.y, I4.z, I4.w}, Dv[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = exp2f(fmaf(s[4 * g + e], c, -Lv[e]));
+          const float p = exp2f(fmaf(s[4 * g + e], c, -Lv[e])) * Iv[e];
           s[4 * g + e] = p;                                   // P
           dp[4 * g + e] = p * (dp[4 * g + e] - Dv[e]);          // dS
         }
@@ -317,7 +322,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32m_bwd_q_kernel(AttnF32Bwd a) {
 #pragma unroll
     for (int st = 0; st < 32; ++st) { qf[st] = qp[2 * st]; dof[st] = op[2 * st]; }
   }
-  const float Lq_ = a.lse[((size_t)b * a.heads + h) * a.Lq + qr];
+  const float2 ml_ = *reinterpret_cast<const float2*>(a.lse + (((size_t)b * a.heads + h) * a.Lq + qr) * 2);
+  const float Lq_ = ml_.x, Iq_ = 1.0f / ml_.y;
   const float Dq_ = a.delta[((size_t)b * a.heads + h) * a.Lq + qr];
   f32x16 dq[2];
 #pragma unroll
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32m_bwd_q_kernel(AttnF32Bwd a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float p = key < a.Lk ? exp2f(fmaf(s[r], c, -Lq_)) : 0.f;
+        const float p = key < a.Lk ? exp2f(fmaf(s[r], c, -Lq_)) * Iq_ : 0.f;
         dp[r] = p * (dp[r] - Dq_);                              // dS^T[key][q]
       }
       // dQ^T[d][q] += K^T[d][key] dS^T[key][q]   (k-step t contracts key kb*32 + (t&3) + 8(t>>2) + 4 lh)

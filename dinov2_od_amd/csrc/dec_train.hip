@@ -981,7 +981,7 @@ size_t carve_ttape(const TDims& d, void* base, TTape* t) {
     b.x = take(M * D); b.y1 = take(M * D); b.qkv = take(M * 3 * D); b.ctx = take(M * D); b.x1 = take(M * D); b.y2 = take(M * D);
     b.pre = take(M * (size_t)d.F1); b.h = take(M * F);
     b.Wqkv = take(3 * D * D); b.Wo = take(D * D); b.W1 = take((size_t)d.F1 * D); b.W2 = take(D * F); b.bqkv = take(3 * D);
-    b.lse = take(M * (size_t)d.H);                 // log-sum-exp of every score row [B, H, N]: the flash-style attention adjoint
+    b.lse = take(2 * M * (size_t)d.H);             // (max, sum) of every score row [B, H, N, 2]: the flash-style attention adjoint
   }
   if (t) *t = tt;
   return off;

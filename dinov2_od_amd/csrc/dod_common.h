@@ -171,8 +171,8 @@ struct AttnF32 {
   int Lq, Lk;                 // rows per batch item
   int B, heads, dh;
   float scale;
-  float* lse = nullptr;       // optional [B, heads, Lq]: log2-domain log-sum-exp of every score row, max_j(s c) + log2(sum_j 2^(s c - max)),
-                              // c = scale log2(e) -- what the flash-style adjoint (launch_attn_f32_bwd) needs; MFMA kernel only
+  float* lse = nullptr;       // optional [B, heads, Lq, 2]: (max_j(s c), sum_j 2^(s c - max)) of every score row, c = scale log2(e) -- what
+                              // the flash-style adjoint (launch_attn_f32_bwd) recomputes the probabilities from; MFMA kernel only
 };
 int launch_attn_f32(const AttnF32& a, hipStream_t s);
 // Adjoint of launch_attn_f32 without materialised scores (attn_f32m.hip; head_dim 64, exact-fp32 MFMA): q | k | v and their gradients

@@ -765,8 +765,8 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
     attr_set = true;
   }
   const char* force = getenv("DINODET_GEMM_TILE");     // "128" / "256": tuning override
-  if (!force && M >= 4096 && N >= 512 && e.act != ACT_GELU && e.act != ACT_SIGMOID && e.rows_per_img == 0 && K % 64 == 0) {   // the 256x256-tile shapes
-    const int t = gemm_tail_split(0, A, lda, W, ldw, M, N, K, e, s);
+  if (!force && M >= 2048 && N >= 512 && e.act != ACT_GELU && e.act != ACT_SIGMOID && e.rows_per_img == 0 && K % 64 == 0) {   // the 256x256-tile shapes
+    const int t = gemm_tail_split(0, A, lda, W, ldw, M, N, K, e, s);      // short last round (M >= 8192), or a grid of a few dozen tiles (M >= 2048)
     if (t >= 0) return t;
   }
   // 256x256x64, 16 waves, two 64-KiB slots (the structure of gemm_x3.hip with k 32..63 in the second planes): measured at

@@ -946,7 +946,12 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   const int nk = K / ktile;
   const bool force = mode == 2;
   int Mmain, R, tiles_r, S = 0;
-  if (kind >= 1 && M >= 2048 && tiles * 2 <= CU + CU / 8) {
+  // plain bf16 (kind 0) has a 256x128 tile for moderately underfilled grids; it takes the K-split only when even that leaves most of
+  // the chip idle -- the decoder's query-side linears, M = B*Q rows (3 200 at batch 32: 39 tiles of 256x256, 78 of 256x128, each
+  // walking K' = 3K = 2 304: 48.5 us on 78 CUs, tools/rocprof_by_grid.py on `bench.py --workload vitb224`).  DINODET_GEMM_KSPLIT0 =
+  // tile-count ceiling as a fraction of the CUs in 1/12ths (default 4: tiles <= CUs / 3; 0 = never)
+  static const int k0frac = [] { const char* v = getenv("DINODET_GEMM_KSPLIT0"); return v ? atoi(v) : 4; }();
+  if (M >= 2048 && (kind >= 1 ? tiles * 2 <= CU + CU / 8 : tiles * 12 <= CU * k0frac)) {
     // (a) an UNDERFILLED single round (the compensated kernels have no smaller tile): 99 tiles of an N = 768 GEMM at M = 8224 leave 157
     // CUs idle -- every tile is K-split so that tiles x S fills the chip (no main launch)
     Mmain = 0; R = M; tiles_r = tiles;
