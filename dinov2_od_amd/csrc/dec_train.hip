@@ -987,11 +987,16 @@ size_t carve_ttape(const TDims& d, void* base, TTape* t) {
   return off;
 }
 struct TScratch { float *dx, *da, *db, *dbig, *dqkv, *dS, *Pd, *T, *U, *dump, *dh, *delta; };
-// head_dim 64 (every DINOv2 variant): the attention adjoint recomputes its scores tile by tile (attn_f32m.hip launch_attn_f32_bwd) -- no
-// [B*H, N, N] score / adjoint scratch.  DINODET_ATTN_BWD_FLASH=0 keeps the batched-GEMM form (A/B, and the form other head sizes take).
+// head_dim 64 (every DINOv2 variant): the attention adjoint may recompute its scores tile by tile (attn_f32m.hip launch_attn_f32_bwd) -- no
+// [B*H, N, N] score / adjoint scratch -- instead of the batched-GEMM form (which other head sizes always take).
+// Taken from 1 024 tokens per image up (518x518 inputs: 19.8 vs 21.9 ms per ViT-B batch-8 step, and no 2 x 720 MB of scratch); below
+// that the batched form is as fast (224x224: 10.0 vs 9.9 ms) and sits closer to a float64 evaluation -- the flash form takes
+// delta = <dO, O> from the forward's rounded output instead of sum_j P dP over the probabilities it multiplies (1.7e-5 vs 5.3e-5 from
+// float64 on the worst LoRA gradient at 1 370 tokens, the PyTorch composite 2.3e-5).  DINODET_ATTN_BWD_FLASH = 0 / 1 forces either.
 inline bool tail_flash_bwd(const TDims& d) {
   static const char* e = getenv("DINODET_ATTN_BWD_FLASH");
-  return d.dh == 64 && !(e && e[0] == '0');
+  if (d.dh != 64 || (e && e[0] == '0')) return false;
+  return (e && e[0] == '1') || d.N >= 1024;
 }
 size_t carve_tscratch(const TDims& d, void* base, TScratch* sc) {
   size_t off = 0;

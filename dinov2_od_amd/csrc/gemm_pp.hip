@@ -946,11 +946,12 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   const int nk = K / ktile;
   const bool force = mode == 2;
   int Mmain, R, tiles_r, S = 0;
-  // plain bf16 (kind 0) has a 256x128 tile for moderately underfilled grids; it takes the K-split only when even that leaves most of
-  // the chip idle -- the decoder's query-side linears, M = B*Q rows (3 200 at batch 32: 39 tiles of 256x256, 78 of 256x128, each
-  // walking K' = 3K = 2 304: 48.5 us on 78 CUs, tools/rocprof_by_grid.py on `bench.py --workload vitb224`).  DINODET_GEMM_KSPLIT0 =
-  // tile-count ceiling as a fraction of the CUs in 1/12ths (default 4: tiles <= CUs / 3; 0 = never)
-  static const int k0frac = [] { const char* v = getenv("DINODET_GEMM_KSPLIT0"); return v ? atoi(v) : 4; }();
+  // plain bf16 (kind 0) has a 256x128 tile for underfilled grids and does NOT take this K-split by default.  Round 3 tried it on the
+  // decoder's query-side linears (M = B*Q = 3 200 rows at batch 32: 39 tiles of 256x256 walking K' = 3K = 2 304, 48.5 us on 78 CUs as
+  // 256x128 tiles): six slices per tile (234 workgroups) + the reduce launch write and re-read 59 MB of fp32 partials, and the forward
+  // gains nothing (`bench.py --workload vitb224`: 7 539 vs 7 571 images/s, vitb518 2 241.7 both ways).  DINODET_GEMM_KSPLIT0 = n enables it
+  // for grids of at most CUs * n / 12 tiles (tuning switch).
+  static const int k0frac = [] { const char* v = getenv("DINODET_GEMM_KSPLIT0"); return v ? atoi(v) : 0; }();
   if (M >= 2048 && (kind >= 1 ? tiles * 2 <= CU + CU / 8 : tiles * 12 <= CU * k0frac)) {
     // (a) an UNDERFILLED single round (the compensated kernels have no smaller tile): 99 tiles of an N = 768 GEMM at M = 8224 leave 157
     // CUs idle -- every tile is K-split so that tiles x S fills the chip (no main launch)
