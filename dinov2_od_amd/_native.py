@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdinodet.so")
 
 DOD_F32, DOD_BF16 = 0, 1
 PREC = {"fp32": 0, "bf16": 1, "fp8": 2, "bf16x3": 3, "fp16x2": 4}
-ACT = {"none": 0, "relu": 1, "gelu": 2, "sigmoid": 3}
+ACT = {"none": 0, "relu": 1, "gelu": 2, "sigmoid": 3, "swiglu_pairs": 4}
 
 
 class DodConfig(C.Structure):

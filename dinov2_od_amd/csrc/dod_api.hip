@@ -25,6 +25,7 @@ struct BLayer {
   float *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;   // fp8 mode: per-output-feature dequant scales
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
   float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
+  bool glu = false;      // SwiGLU, bf16 / fp8 modes: W1 / b1 hold weights_in with the (x1_i, x2_i) rows INTERLEAVED; the gate runs in the GEMM epilogue
 };
 struct DLayer {
   float *in_w = nullptr, *in_b = nullptr, *out_w = nullptr, *out_b = nullptr;
@@ -318,8 +319,18 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
     L.Wo = packw(P.eff_weight(lp + "attention.output.dense", D, D), D, D, &L.so, &L.eo, true);
     L.bo = P.eff_bias(lp + "attention.output.dense", D);
     if (c.swiglu) {
-      L.W1 = packw(P.eff_weight(lp + "mlp.weights_in", 2 * F, D), 2 * F, D, &L.s1, &L.e1, true);
+      const float* w_in = P.eff_weight(lp + "mlp.weights_in", 2 * F, D);
       L.b1 = P.eff_bias(lp + "mlp.weights_in", 2 * F);
+      // bf16 / fp8 operands: hidden = silu(x1) * x2 (modeling_dinov2.py:310-314) is evaluated in the weights_in GEMM's epilogue
+      // (GemmEpi::glu) on interleaved column pairs -- rows of the weight and the bias re-ordered once here (x1_i, x2_i adjacent; the
+      // fp8 per-feature scales are computed on the re-ordered rows).  The compensated and fp32 modes keep the separate gate kernel.
+      static const bool glu_off = getenv("DINODET_NO_FUSED_GLU") != nullptr;
+      if (w_in && L.b1 && is_bf16(h) && !is_x3(h) && !glu_off) {
+        float* wi = P.alloc<float>((size_t)2 * F * D, true);
+        float* bi = P.alloc<float>((size_t)2 * F);
+        if (wi && bi && !launch_interleave_halves(w_in, wi, F, D, s) && !launch_interleave_halves(L.b1, bi, F, 1, s)) { w_in = wi; L.b1 = bi; L.glu = true; }
+      }
+      L.W1 = packw(w_in, 2 * F, D, &L.s1, &L.e1, true);
       L.W2 = packw(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, &L.s2, &L.e2, true);
       L.b2 = P.eff_bias(lp + "mlp.weights_out", D);
     } else {
@@ -639,7 +650,12 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
     }
     if (f8) {
       { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, (unsigned char*)ws.y, ws.rs)); }
-      if (g.swiglu) {
+      if (g.swiglu && L.glu) {     // gate fused into the GEMM epilogue: [M, F] bf16, then the row quantisation of the MLP-out operand
+        GemmEpi eg = epi(L.b1, nullptr, ws.hbuf, F); eg.glu = 1;
+        rc = linear8(h, ws.y, ws.rs, L.W1, L.s1, M, 2 * F, D, eg, s); if (rc) return rc;
+        KCHK(h, launch_quant_rows_fp8(ws.hbuf, 1, F, M, F, (unsigned char*)ws.gated, F, ws.rs, s));
+        rc = linear8(h, ws.gated, ws.rs, L.W2, L.s2, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
+      } else if (g.swiglu) {
         rc = linear8(h, ws.y, ws.rs, L.W1, L.s1, M, 2 * F, D, epi(L.b1, nullptr, ws.hbuf, 2 * F), s); if (rc) return rc;
         KCHK(h, launch_swiglu_fp8((const bf16_t*)ws.hbuf, M, F, (unsigned char*)ws.gated, ws.rs, s));
         rc = linear8(h, ws.gated, ws.rs, L.W2, L.s2, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
@@ -651,7 +667,11 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
       continue;
     }
     { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, yf, yb, s)); }
-    if (g.swiglu) {                                                                                            // K7g
+    if (g.swiglu && L.glu && bf) {                                                                             // K7g, gate in the epilogue
+      GemmEpi eg = epi(L.b1, nullptr, ws.gated, F); eg.glu = 1;
+      rc = linear(h, true, ws.y, D, L.W1, D, M, 2 * F, D, eg, s); if (rc) return rc;
+      rc = linear(h, true, ws.gated, F, L.W2, F, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
+    } else if (g.swiglu) {                                                                                     // K7g
       rc = linear(h, bf, ws.y, D, L.W1, D, M, 2 * F, D, epi(L.b1, bf ? nullptr : (float*)ws.hbuf, bf ? ws.hbuf : nullptr, 2 * F), s); if (rc) return rc;
       KCHK(h, launch_swiglu(bf ? nullptr : (const float*)ws.hbuf, bf ? (const bf16_t*)ws.hbuf : nullptr, M, F, bf ? nullptr : (float*)ws.gated, bf ? (bf16_t*)ws.gated : nullptr, s));
       rc = linear(h, bf, ws.gated, F, L.W2, F, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
@@ -1047,6 +1067,10 @@ int dod_op_linear(int in_dtype, const void* A, int lda, const void* W, int ldw, 
                   const float* scale, const float* resid, int ldr, void* out, int out_dtype, int ldc, int act, void* stream) {
   if (!A || !W || !out) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
   GemmEpi e = epi(bias, out_dtype == DOD_F32 ? (float*)out : nullptr, out_dtype == DOD_BF16 ? out : nullptr, ldc, act, scale, resid, ldr);
+  if (act == DOD_ACT_SWIGLU_PAIRS) {      // interleaved (x1_i, x2_i) columns -> silu(x1_i) * x2_i at column i (bf16 operands and output only)
+    if (in_dtype != DOD_BF16 || out_dtype != DOD_BF16 || scale || resid || (N & 7)) return fail(nullptr, DOD_ERR_INVALID, "DOD_ACT_SWIGLU_PAIRS: bf16 in / out, N % 8 == 0, no scale / residual");
+    e.act = ACT_NONE; e.glu = 1;
+  }
   int r = in_dtype == DOD_BF16 ? launch_gemm_bf16((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, e, (hipStream_t)stream)
                                : launch_gemm_f32((const float*)A, lda, (const float*)W, ldw, M, N, K, e, (hipStream_t)stream);
   if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);

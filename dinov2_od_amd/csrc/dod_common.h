@@ -116,6 +116,9 @@ struct GemmEpi {
   int kslice_len;         //   product goes to out_f32 + slice * kslice_stride (no other epilogue term may be set)
   long long kslice_stride;
   int rb;                 // residual epilogue of the 512-thread 256x256 kernels: residual loads in flight per thread (0 = 4; 8, 16)
+  int glu;                // with out_bf16 (plain layout): the GEMM's columns are INTERLEAVED SwiGLU pairs (2i: x1_i, 2i + 1: x2_i;
+                          //   Dinov2SwiGLUFFN, modeling_dinov2.py:310-314) and the epilogue writes silu(x1_i) * x2_i to column i: N / 2 columns at
+                          //   row pitch ldc -- the gate costs no pass over the [M, 2F] intermediate
 };
 
 // ----------------------------------------------------------------------------- launchers (all enqueue on `s`, no sync)
@@ -198,6 +201,8 @@ int launch_patch_embed(const void* img, int u8, int B, int H, int W, int p, cons
 int launch_cls_row(const float* cls, const float* pos, float* x, int B, int N, int D, hipStream_t s);
 // bicubic resize of the patch position table (torch upsample_bicubic2d, A=-0.75, align_corners=False)
 int launch_pos_resize(const float* pos_in, int G, int gh, int gw, int D, float* pos_out, hipStream_t s);
+// dst [2F, cols] = rows of src [2F, cols] interleaved: dst[2i] = src[i], dst[2i + 1] = src[F + i] (SwiGLU pairs adjacent: GemmEpi::glu)
+int launch_interleave_halves(const float* src, float* dst, int F, int cols, hipStream_t s);
 // silu(x1)*x2 over [rows, 2*Fh] -> [rows, Fh]
 int launch_swiglu(const float* in_f32, const bf16_t* in_bf16, int rows, int Fh, float* out_f32, bf16_t* out_bf16, hipStream_t s);
 int launch_cast_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);

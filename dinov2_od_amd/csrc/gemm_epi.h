@@ -60,6 +60,8 @@ __device__ __forceinline__ void tile_map(int b, int tiles_m, int tiles_n, int mo
   *tm_out = tm; *tn_out = tn;
 }
 
+__device__ __forceinline__ float silu_mul(float a, float b) { return a / (1.0f + expf(-a)) * b; }     // Dinov2SwiGLUFFN: silu(x1) * x2
+
 // ---- epilogue, staged through LDS so that HBM sees whole rows ---------------------------------------
 // Phase 1 (stage_acc): a lane owns output row m and its register quads 4 consecutive n: it applies
 // bias / activation / LayerScale (float4 per-n parameter reads) and writes float4s into an fp32 LDS
@@ -191,6 +193,8 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
       bf16_t* o = e.out_bf16 + orow * e.ldc + n;
       *reinterpret_cast<uint2*>(o) = hi;
       *reinterpret_cast<uint2*>(o - e.out_split) = lo;
+    } else if (e.glu) {             // interleaved SwiGLU pairs: columns n .. n+3 = (x1, x2, x1, x2) -> two gated outputs at n / 2
+      *reinterpret_cast<unsigned*>(e.out_bf16 + orow * e.ldc + (n >> 1)) = pack2bf(silu_mul(v.x, v.y), silu_mul(v.z, v.w));
     } else {
       uint2 o;
       o.x = pack2bf(v.x, v.y);
@@ -244,6 +248,13 @@ __device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, con
       char* p8 = row + h2_off8(N, n);
       *reinterpret_cast<uint2*>(p8) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(p8 + 16) = make_uint2(l0, l1);
+      continue;
+    }
+    if (e.glu) {                    // interleaved SwiGLU pairs: eight columns -> four gated outputs at n / 2
+      uint2 g;
+      g.x = pack2bf(silu_mul(v.x, v.y), silu_mul(v.z, v.w));
+      g.y = pack2bf(silu_mul(u.x, u.y), silu_mul(u.z, u.w));
+      *reinterpret_cast<uint2*>(e.out_bf16 + (size_t)m * e.ldc + (n >> 1)) = g;
       continue;
     }
     uint4 hi;

@@ -420,3 +420,19 @@ int launch_split3(const float* in, int ld_in, bf16_t* out, int rows, int K, int 
   hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, s, in, ld_in, out, rows, K, mode);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
+
+// dst[2i] = src[i], dst[2i + 1] = src[F + i] over rows of `cols` floats (weight pack time: SwiGLU pairs adjacent for GemmEpi::glu)
+__global__ void interleave_halves_kernel(const float* __restrict__ src, float* __restrict__ dst, int F, int cols) {
+  const size_t total = (size_t)2 * F * cols;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = idx / cols; const int c = (int)(idx - r * cols);
+    const size_t sr = (r & 1) ? (size_t)F + (r >> 1) : (r >> 1);
+    dst[idx] = src[sr * cols + c];
+  }
+}
+int launch_interleave_halves(const float* src, float* dst, int F, int cols, hipStream_t s) {
+  if (F <= 0 || cols <= 0) return 1;
+  const size_t total = (size_t)2 * F * cols;
+  hipLaunchKernelGGL(interleave_halves_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, s, src, dst, F, cols);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}

@@ -149,7 +149,9 @@ int dod_profile(dod_handle* h, int enable);
 int dod_profile_read(dod_handle* h, int cls, double* ms, double* flops, int* launches);
 
 /* ---- stateless operator entry points (the same kernels the forward uses; for parity tests) ------ */
-enum dod_act { DOD_ACT_NONE = 0, DOD_ACT_RELU = 1, DOD_ACT_GELU = 2, DOD_ACT_SIGMOID = 3 };
+enum dod_act { DOD_ACT_NONE = 0, DOD_ACT_RELU = 1, DOD_ACT_GELU = 2, DOD_ACT_SIGMOID = 3,
+               DOD_ACT_SWIGLU_PAIRS = 4 };   /* dod_op_linear only: the N columns are interleaved SwiGLU pairs (2i: x1_i, 2i+1: x2_i); the
+                                                 output has N / 2 columns silu(x1_i) * x2_i at row pitch ldc (bf16 in / out) */
 
 /* out[M,N] = act(A[M,K] W[N,K]^T + bias) * scale + resid ; A, W of dtype `in_dtype`; bias/scale/resid fp32 or NULL */
 int dod_op_linear(int in_dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K,

@@ -239,10 +239,10 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
         y = _layernorm(h, sd(lp + "norm2.weight"), sd(lp + "norm2.bias"), bb.ln_eps)
         if bb.swiglu:
             z = _maybe_lora_linear(sd, lp + "mlp.weights_in", y, a, emu_lin, f8)
-            if f8:
-                z = _bf(z)              # the fp8 path stores the MLP-in output in bf16 before the SwiGLU kernel
             x1, x2 = z.chunk(2, dim=-1)
             z = F.silu(x1) * x2
+            if f8:
+                z = _bf(z)              # the fp8 path gates in the MLP-in GEMM's epilogue (fp32), stores the hidden rows in bf16, then quantises them
             z = _maybe_lora_linear(sd, lp + "mlp.weights_out", z, a, emu_lin, f8)
         else:
             z = _maybe_lora_linear(sd, lp + "mlp.fc1", y, a, emu_lin, f8)

@@ -268,3 +268,23 @@ def test_gemm_f32x_batched_attention_views(G, B, H, Q, dh):
     _gemm_f32x(S, Qp, 1, ss * H, ss, qd, ld, 1, qs, dh, dK, D, Q * D, dh, Q, dh, Q, B * H, H, 1.0, 0, 1)
     dK_ref = (S_ref.transpose(-1, -2) @ q).permute(0, 2, 1, 3).reshape(B * Q, D)
     assert rel_err(dK.cpu().numpy(), dK_ref.numpy()) < 3e-6
+
+
+@pytest.mark.parametrize("M,F,K", [(300, 64, 128), (1370, 1024, 768), (4400, 4096, 1536)])
+def test_linear_swiglu_pairs_epilogue(M, F, K):
+    """GemmEpi::glu (the SwiGLU gate of Dinov2SwiGLUFFN, modeling_dinov2.py:310-314, evaluated in the weights_in GEMM's epilogue): the weight
+    rows arrive interleaved (x1_i, x2_i adjacent), the output is silu(x1) * x2 in F columns.  Against the fp64 evaluation of the same bf16
+    operands on the UN-interleaved weight; covers the small-tile, the 256x128 and the 256x256 ping-pong kernels' epilogues."""
+    from tests import gpu_util as G
+    L = nat.lib()
+    A = torch.from_numpy(synth.normal(21, f"glu.A.{M}.{K}", (M, K), 1.0)).cuda().bfloat16()
+    W = torch.from_numpy(synth.normal(21, f"glu.W.{F}.{K}", (2 * F, K), 0.05)).cuda().bfloat16()
+    bias = torch.from_numpy(synth.normal(21, f"glu.b.{F}", (2 * F,), 0.5)).cuda()
+    Wi = torch.stack([W[:F], W[F:]], dim=1).reshape(2 * F, K).contiguous()          # rows 2i = x1_i, 2i + 1 = x2_i
+    bi = torch.stack([bias[:F], bias[F:]], dim=1).reshape(2 * F).contiguous()
+    out = torch.empty(M, F, dtype=torch.bfloat16, device="cuda")
+    nat.check(L.dod_op_linear(nat.DOD_BF16, nat.ptr(A), K, nat.ptr(Wi), K, M, 2 * F, K, nat.ptr(bi), None, None, 0, nat.ptr(out), nat.DOD_BF16, F,
+                              nat.ACT["swiglu_pairs"], nat.stream_ptr()))
+    z = A.double().cpu() @ W.double().cpu().t() + bias.double().cpu()
+    want = torch.nn.functional.silu(z[:, :F]) * z[:, F:]
+    assert rel_err(out.float().cpu().numpy(), want.numpy()) < 2 ** -8
