@@ -325,7 +325,10 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
       // (GemmEpi::glu) on interleaved column pairs -- rows of the weight and the bias re-ordered once here (x1_i, x2_i adjacent; the
       // fp8 per-feature scales are computed on the re-ordered rows).  The compensated and fp32 modes keep the separate gate kernel.
       static const bool glu_off = getenv("DINODET_NO_FUSED_GLU") != nullptr;
-      if (w_in && L.b1 && is_bf16(h) && !is_x3(h) && !glu_off) {
+      // (round 3b: the compensated modes too -- their gate was three passes over fp32 [M, 2F] / [M, F] buffers: 4.9 GB per ViT-g block at 32
+      // images; the epilogue now writes the pair / H2 operand rows of weights_out directly.  H2 rows need F % 32 == 0 and whole quads.)
+      const bool glu_ok = is_x3(h) ? (F % 32 == 0) : is_bf16(h);
+      if (w_in && L.b1 && glu_ok && !glu_off) {
         float* wi = P.alloc<float>((size_t)2 * F * D, true);
         float* bi = P.alloc<float>((size_t)2 * F);
         if (wi && bi && !launch_interleave_halves(w_in, wi, F, D, s) && !launch_interleave_halves(L.b1, bi, F, 1, s)) { w_in = wi; L.b1 = bi; L.glu = true; }
@@ -613,7 +616,11 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
       }
       rc = lin(ws.ctx, L.Wo, L.eo, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D)); if (rc) return rc;
       { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3, h2 ? 1 : 0)); }
-      if (g.swiglu) {
+      if (g.swiglu && L.glu) {      // gate in the weights_in epilogue, written as the pair / H2 operand rows of weights_out
+        GemmEpi e1 = epi(L.b1, nullptr, ws.hbuf, 2 * F); e1.glu = 1;
+        if (h2) e1.out_h2 = 1; else e1.out_split = -F;
+        rc = lin(y3, L.W1, L.e1, 2 * F, D, e1); if (rc) return rc;
+      } else if (g.swiglu) {
         rc = lin(y3, L.W1, L.e1, 2 * F, D, epi(L.b1, (float*)ws.hbuf, nullptr, 2 * F)); if (rc) return rc;
         KCHK(h, launch_swiglu((const float*)ws.hbuf, nullptr, M, F, (float*)ws.gated, nullptr, s));
         KCHK(h, split((const float*)ws.gated, F, ws.hbuf));

@@ -166,6 +166,12 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
     }
     if (e.out_f32) {
       *reinterpret_cast<float4*>(e.out_f32 + orow * e.ldc + n) = v;
+    } else if (e.glu) {             // interleaved SwiGLU pairs: columns n .. n+3 = (x1, x2, x1, x2) -> two gated outputs at column n / 2
+      const float g0 = silu_mul(v.x, v.y), g1 = silu_mul(v.z, v.w);         // (H2 rows need whole quads: launchers route them to drain_tile_bf16x8)
+      const unsigned hi = pack2bf(g0, g1);
+      bf16_t* og = e.out_bf16 + orow * e.ldc + (n >> 1);
+      *reinterpret_cast<unsigned*>(og) = hi;
+      if (e.out_split < 0) *reinterpret_cast<unsigned*>(og - e.out_split) = pack2bf(g0 - __uint_as_float(hi << 16), g1 - __uint_as_float(hi & 0xffff0000u));
     } else if (e.out_h2) {          // H2 operand row of the next GEMM (dod_common.h)
       uint2 f16; unsigned hi8, lo8;
       h2_quad(v, 1.0f, f16, hi8, lo8);
@@ -193,8 +199,6 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
       bf16_t* o = e.out_bf16 + orow * e.ldc + n;
       *reinterpret_cast<uint2*>(o) = hi;
       *reinterpret_cast<uint2*>(o - e.out_split) = lo;
-    } else if (e.glu) {             // interleaved SwiGLU pairs: columns n .. n+3 = (x1, x2, x1, x2) -> two gated outputs at n / 2
-      *reinterpret_cast<unsigned*>(e.out_bf16 + orow * e.ldc + (n >> 1)) = pack2bf(silu_mul(v.x, v.y), silu_mul(v.z, v.w));
     } else {
       uint2 o;
       o.x = pack2bf(v.x, v.y);
@@ -250,11 +254,30 @@ __device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, con
       *reinterpret_cast<uint2*>(p8 + 16) = make_uint2(l0, l1);
       continue;
     }
-    if (e.glu) {                    // interleaved SwiGLU pairs: eight columns -> four gated outputs at n / 2
+    if (e.glu) {                    // interleaved SwiGLU pairs: eight columns -> four gated outputs at column n / 2 of an N / 2-column row
+      const float4 gq = make_float4(silu_mul(v.x, v.y), silu_mul(v.z, v.w), silu_mul(u.x, u.y), silu_mul(u.z, u.w));
+      const int nh = n >> 1;
+      if (e.out_h2) {               // H2 operand row (fp16x2 mode)
+        uint2 f16; unsigned hi8, lo8;
+        h2_quad(gq, 1.0f, f16, hi8, lo8);
+        char* row = reinterpret_cast<char*>(e.out_bf16) + (size_t)m * e.ldc * 2;
+        *reinterpret_cast<uint2*>(row + 2 * nh) = f16;
+        char* p8 = row + h2_off8(N >> 1, nh);
+        *reinterpret_cast<unsigned*>(p8) = hi8;
+        *reinterpret_cast<unsigned*>(p8 + 16) = lo8;
+        continue;
+      }
       uint2 g;
-      g.x = pack2bf(silu_mul(v.x, v.y), silu_mul(v.z, v.w));
-      g.y = pack2bf(silu_mul(u.x, u.y), silu_mul(u.z, u.w));
-      *reinterpret_cast<uint2*>(e.out_bf16 + (size_t)m * e.ldc + (n >> 1)) = g;
+      g.x = pack2bf(gq.x, gq.y);
+      g.y = pack2bf(gq.z, gq.w);
+      bf16_t* og = e.out_bf16 + (size_t)m * e.ldc + nh;
+      *reinterpret_cast<uint2*>(og) = g;
+      if (e.out_split < 0) {        // pair layout [hi | lo] (bf16x3 mode), each half -out_split columns wide
+        uint2 lo;
+        lo.x = pack2bf(gq.x - __uint_as_float(g.x << 16), gq.y - __uint_as_float(g.x & 0xffff0000u));
+        lo.y = pack2bf(gq.z - __uint_as_float(g.y << 16), gq.w - __uint_as_float(g.y & 0xffff0000u));
+        *reinterpret_cast<uint2*>(og - e.out_split) = lo;
+      }
       continue;
     }
     uint4 hi;

@@ -825,7 +825,9 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
   if (e.out_f32 && e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
-  if (e.out_h2 && (N % 32 != 0 || e.ldc < 2 * N || e.ldc % 8 != 0 || e.out_split != 0)) return 2;
+  { const int No = e.glu ? N / 2 : N;     // columns of the output row (GemmEpi::glu: the gate halves them)
+    if (e.out_h2 && (No % 32 != 0 || e.ldc < 2 * No || e.ldc % 8 != 0 || e.out_split != 0)) return 2;
+    if (e.glu && e.out_h2 && (N % 8 != 0)) return 2; }
   { const int t = gemm_tail_split(2, A, lda, W, ldw, M, N, K, e, s); if (t >= 0) return t; }
   constexpr int LDSH2 = (128 * (PPN * 4 + 16)) > H2_LDS ? (128 * (PPN * 4 + 16)) : H2_LDS;
   static bool attr_set[16] = {};
