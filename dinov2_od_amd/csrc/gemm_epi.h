@@ -243,17 +243,6 @@ __device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, con
     }
     v.x *= s0.x; v.y *= s0.y; v.z *= s0.z; v.w *= s0.w;
     u.x *= s1.x; u.y *= s1.y; u.z *= s1.z; u.w *= s1.w;
-    if (e.out_h2) {                 // H2 operand row of the next GEMM (dod_common.h): 16 B of fp16, 8 + 8 B of e4m3
-      uint2 fa, fb; unsigned h0, l0, h1, l1;
-      h2_quad(v, 1.0f, fa, h0, l0);
-      h2_quad(u, 1.0f, fb, h1, l1);
-      char* row = reinterpret_cast<char*>(e.out_bf16) + (size_t)m * e.ldc * 2;
-      *reinterpret_cast<uint4*>(row + 2 * n) = make_uint4(fa.x, fa.y, fb.x, fb.y);
-      char* p8 = row + h2_off8(N, n);
-      *reinterpret_cast<uint2*>(p8) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(p8 + 16) = make_uint2(l0, l1);
-      continue;
-    }
     if (e.glu) {                    // interleaved SwiGLU pairs: eight columns -> four gated outputs at column n / 2 of an N / 2-column row
       const float4 gq = make_float4(silu_mul(v.x, v.y), silu_mul(v.z, v.w), silu_mul(u.x, u.y), silu_mul(u.z, u.w));
       const int nh = n >> 1;
@@ -278,6 +267,17 @@ __device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, con
         lo.y = pack2bf(gq.z - __uint_as_float(g.y << 16), gq.w - __uint_as_float(g.y & 0xffff0000u));
         *reinterpret_cast<uint2*>(og - e.out_split) = lo;
       }
+      continue;
+    }
+    if (e.out_h2) {                 // H2 operand row of the next GEMM (dod_common.h): 16 B of fp16, 8 + 8 B of e4m3
+      uint2 fa, fb; unsigned h0, l0, h1, l1;
+      h2_quad(v, 1.0f, fa, h0, l0);
+      h2_quad(u, 1.0f, fb, h1, l1);
+      char* row = reinterpret_cast<char*>(e.out_bf16) + (size_t)m * e.ldc * 2;
+      *reinterpret_cast<uint4*>(row + 2 * n) = make_uint4(fa.x, fa.y, fb.x, fb.y);
+      char* p8 = row + h2_off8(N, n);
+      *reinterpret_cast<uint2*>(p8) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(p8 + 16) = make_uint2(l0, l1);
       continue;
     }
     uint4 hi;
