@@ -154,10 +154,14 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
 // s_memrealtime (100 MHz) at kernel entry, at the end of the tile loop}; the exit time is the next workgroup's entry
 __device__ unsigned long long* g_attn_stamps = nullptr;
 
+// K/V ring, [slot][K|V][64 rows][128 B] = 48 KiB: ONE file-scope array, so that both bodies of the fused kernel address the same
+// compile-time-constant LDS locations (a pointer parameter cost the 64-rows-per-wave body three registers and a spill)
+__shared__ __attribute__((aligned(16))) char g_attn_smem[3 * 2 * AT_KV * 128];
+// the kernel body for workgroup index `blk_` of a launch over query rows [q_lo, q_hi)
 template <int AT_NQ>
-__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                        int N, int heads, int npairs, float scale_log2e, int q_lo, int q_hi) {
-  __shared__ __attribute__((aligned(16))) char smem[3 * 2 * AT_KV * 128];   // [slot][K|V][64 rows][128 B] = 48 KiB
+__device__ __forceinline__ void attn_bf16_body(const int blk_, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                               int N, int heads, int npairs, float scale_log2e, int q_lo, int q_hi) {
+  char* const smem = g_attn_smem;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int D = heads * 64, ld = 3 * D;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
   const int nqb = (q_hi - q_lo + AT_WAVES * AT_QW - 1) / (AT_WAVES * AT_QW);      // query rows [q_lo, q_hi) of every (image, head); keys 0..N-1
   int b, h, qb;
   {
-    const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+    const int L = blk_, xcd = L & 7, s = L >> 3;
     const int pair = (s / nqb) * 8 + xcd;
     qb = s - (s / nqb) * nqb;
     if (pair >= npairs) return;            // grid is padded to a multiple of 8 pairs
@@ -288,6 +292,21 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
   }
 }
 
+template <int AT_NQ>
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                        int N, int heads, int npairs, float scale_log2e, int q_lo, int q_hi) {
+  attn_bf16_body<AT_NQ>(blockIdx.x, qkv, ctx, N, heads, npairs, scale_log2e, q_lo, q_hi);
+}
+// ONE launch for a sequence whose last 256-row block is short (N = 1370: 5 blocks + 90 rows): workgroups [0, main_blocks) run the
+// 64-rows-per-wave body over rows [0, q_main), the workgroups behind them the 32-rows-per-wave body over the remainder -- dispatched
+// last, they fill the main part's end-of-kernel bubble instead of costing a launch of their own (round 3: the separate tail launch
+// took 62.6 us per layer for 6.6 % of the rows, profiles/r03_bench_bf16_kernel_stats.csv).  main_blocks % 8 == 0 keeps both XCD maps.
+__global__ __launch_bounds__(256, 2) void attn_bf16_fused_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                              int N, int heads, int npairs, float scale_log2e, int main_blocks, int q_main) {
+  if ((int)blockIdx.x < main_blocks) attn_bf16_body<2>(blockIdx.x, qkv, ctx, N, heads, npairs, scale_log2e, 0, q_main);
+  else attn_bf16_body<1>((int)blockIdx.x - main_blocks, qkv, ctx, N, heads, npairs, scale_log2e, q_main, N);
+}
+
 extern "C" int dod_debug_attn_stamps(void* dev_buf) {
   unsigned long long* p = (unsigned long long*)dev_buf;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 4;
@@ -309,8 +328,13 @@ int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, fl
     const bool split = (tse ? tse[0] != '0' : true) && rem > 0 && rem <= AT_WAVES * 32 && N > AT_WAVES * 64;
     const int q_main = split ? N - rem : N;
     const int nqb = (q_main + AT_WAVES * 64 - 1) / (AT_WAVES * 64);
-    hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, 0, q_main);
-    if (split) hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, q_main, N);
+    static const char* fse = getenv("DINODET_ATTN_FUSED_TAIL");      // "0": the two-launch form (A/B)
+    if (split && !(fse && fse[0] == '0')) {
+      hipLaunchKernelGGL(attn_bf16_fused_kernel, dim3(pairs8 * nqb + pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, pairs8 * nqb, q_main);
+    } else {
+      hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, 0, q_main);
+      if (split) hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, q_main, N);
+    }
   } else {
     const int nqb = (N + AT_WAVES * 32 - 1) / (AT_WAVES * 32);
     hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, 0, N);
