@@ -808,7 +808,14 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   //   256x128x32 with v_mfma_f32_16x16x32_bf16, two workgroups per CU: QKV 703, out-proj 437, fc1 646, fc2 643 TFLOP/s
   //   same tile with 32x32x16: 651 / 405 / 607 / 621;  256x256 (one per CU): 624 / 342 / 554 / 619-643
   // -> the 16x16x32 kernel for every large-M shape; 128x128 for small M (decoder memory at small batch, tests).
-  const bool m16 = force ? (force[0] == '8') : (M >= 1024 && N >= 128);
+  // a grid of a few dozen 256x128 tiles (the decoder's query-side linears: B*Q = 3 200 rows at batch 32 -> 78 workgroups walking K' = 3K
+  // = 2 304) leaves most CUs idle, and one workgroup per CU pulls its operands at the per-CU staging rate whatever its tile: the 128x128
+  // kernel puts the same bytes on twice as many CUs.  tools/bench_small_m.py, M = 3200: N = 768 41.5 -> 30.9 us, N = 1024 42.7 -> 31.9,
+  // K = 3072 53.9 -> 38.7; N = 2304 (234 tiles) 47.8 vs 48.4: stays.  DINODET_GEMM_SMALLGRID=0 restores the round-2 choice (A/B).
+  static const bool smallgrid = [] { const char* v = getenv("DINODET_GEMM_SMALLGRID"); return !(v && v[0] == '0'); }();
+  const long tiles5 = (long)((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
+  const bool few = smallgrid && tiles5 * 2 <= 256 + 64;
+  const bool m16 = force ? (force[0] == '8') : (M >= 1024 && N >= 128 && !few);
   const bool mid = force ? (force[0] == '5') : false;
   const bool big = force ? (force[0] == '2') : false;
   // 16-wave 256x256 for long K (fc2: 581 vs 622 us at M = 87680): its 130 us fixed cost only pays off there

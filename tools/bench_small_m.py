@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Plain-bf16 GEMM at the decoder's query-side shapes (few thousand rows, K' = 3K of the split product): tile choice A/B through
+DINODET_GEMM_TILE (read per call).  Usage: python tools/bench_small_m.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dinov2_od_amd import _native as nat
+from tools.bench_ops import timeit
+L = nat.lib(); dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+tiles = [t for t in os.environ.get("TILES", "default,128,8").split(",")]
+for M in [int(v) for v in os.environ.get("MS", "800,2400,3200,4800,6400,9600").split(",")]:
+    for N, K in ((768, 2304), (2304, 2304), (1024, 2304), (768, 3072), (768, 768)):
+        A = (torch.randn(M, K, generator=g) * 0.5).to(dev).to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+        bias = torch.randn(N, generator=g).to(dev)
+        out = torch.empty(M, N, device=dev, dtype=torch.float32)
+        row = []
+        ref = None
+        for t in tiles:
+            if t == "default": os.environ.pop("DINODET_GEMM_TILE", None)
+            else: os.environ["DINODET_GEMM_TILE"] = t
+            f = lambda: L.dod_op_linear(1, nat.ptr(A), K, nat.ptr(W), K, M, N, K, nat.ptr(bias), None, None, 0, nat.ptr(out), 0, N, 0, nat.stream_ptr())
+            rc = f(); torch.cuda.synchronize()
+            if rc: row.append(f"{t}: rc={rc}"); continue
+            o = out.clone()
+            if ref is None: ref = o
+            d = (o - ref).abs().max().item()
+            dt = timeit(f, iters=20)
+            row.append(f"{t}: {dt*1e6:6.1f} us {2.0*M*N*K/dt/1e12:6.1f} TF d={d:.1e}")
+        os.environ.pop("DINODET_GEMM_TILE", None)
+        print(f"M={M:5d} N={N:4d} K={K:4d} | " + " | ".join(row), flush=True)
