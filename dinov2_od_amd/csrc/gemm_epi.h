@@ -29,7 +29,15 @@ __device__ __forceinline__ void tile_map(int b, int tiles_m, int tiles_n, int mo
   const int GM = mode & 0xff;
   const int nwg = tiles_m * tiles_n;
   int tm, tn;
-  if (mode & 0x200) {
+  if (mode & 0x400) {
+    // weight-resident map (tiles_n even; grid = 8 * ceil(tiles_m / 4) * tiles_n / 2, padded: tm = -1 -> the workgroup exits): XCD x owns
+    // n-half x & 1 -- half the weight matrix stays in its L2 -- and every fourth m-tile; it walks n fastest, so the tiles that share an
+    // A panel run at the same time and the panel streams through the L2 once per half
+    const int xcd = b & 7, idx = b >> 3, hn = tiles_n >> 1;
+    tm = (idx / hn) * 4 + (xcd >> 1);
+    tn = (xcd & 1) * hn + idx % hn;
+    if (tm >= tiles_m) tm = -1;
+  } else if (mode & 0x200) {
     const int per_group = GM * tiles_n;
     const int nfull = tiles_m / (8 * GM);                  // full chunks
     const int body = nfull * 8 * per_group;
@@ -56,7 +64,7 @@ __device__ __forceinline__ void tile_map(int b, int tiles_m, int tiles_n, int mo
     tm = first_m + in_g % gsz;
     tn = in_g / gsz;
   }
-  if (mode & 0x100) tm = tiles_m - 1 - tm;
+  if ((mode & 0x100) && tm >= 0) tm = tiles_m - 1 - tm;
   *tm_out = tm; *tn_out = tn;
 }
 

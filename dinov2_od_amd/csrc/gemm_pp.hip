@@ -208,6 +208,7 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
   if (stamps) { ts0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
   int tm, tn;
   tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
+  if (tm < 0) return;                              // padding of the weight-resident map's grid
   const int m0 = tm * PPM, n0 = tn * PPN;
   // K slice (gemm_tail_split): this workgroup computes k in [kbase, kbase + Kl) and writes its fp32 partial to its own slab
   const int Kl = e_.ksplit > 1 ? e_.kslice_len : K;
@@ -761,6 +762,17 @@ int launch_gemm_bf16_pp(const bf16_t* A, int lda, const bf16_t* W, int ldw, int 
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
+// weight-resident tile map (gemm_epi.h tile_map, mode bit 0x400) for the m-phased ping-pong kernels: DINODET_GEMM_WRES = 1 (read per launch)
+static bool wres_on() {
+  const char* v = getenv("DINODET_GEMM_WRES");
+  return v && v[0] == '1';
+}
+static int wres_grid(int M, int N, int* gm) {
+  const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
+  if (wres_on() && tiles_n % 2 == 0 && tiles_m >= 32) { *gm = (*gm & ~0x300) | 0x400; return 8 * ((tiles_m + 3) / 4) * (tiles_n / 2); }
+  return tiles_m * tiles_n;
+}
+
 // residual loads in flight per thread in the in-place residual epilogue of the 512-thread kernels (gemm_epi.h drain_resid):
 // DINODET_EPI_RB = 4 | 8 | 16 (read per launch: A/B in one process)
 static int epi_rb() {
@@ -788,8 +800,8 @@ int launch_gemm_bf16_ppm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
   ppm_attr();
-  const int gm = gemm_tile_mode();
-  const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
+  int gm = gemm_tile_mode();
+  const int tiles = wres_grid(M, N, &gm);
   const char* f_ = getenv("DINODET_GEMM_TILE");
   GemmEpi e2 = e;
   if (!e2.rb) e2.rb = epi_rb();
@@ -810,8 +822,8 @@ int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int 
   if (getenv("DINODET_DEBUG_NOOUT")) { e2.ldc = 0; e2.ldr = 0; }   // tuning only: every output row aliases row 0
   ppm_attr();
   if (getenv("DINODET_DEBUG_LDA0")) lda = 0;      // tuning only: every A row aliases row 0 (A traffic becomes cache hits)
-  const int gm = gemm_tile_mode();
-  const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
+  int gm = gemm_tile_mode();
+  const int tiles = wres_grid(M, N, &gm);
   const char* v_ = getenv("DINODET_X3_TILE");
   if (v_ && v_[0] == 'p' && v_[1] == 'd') hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, true>), dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e2, gm);
   else hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, false>), dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e2, gm);

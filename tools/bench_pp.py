@@ -22,6 +22,14 @@ def set_variant(v):
     if "@" in v:                               # "<tile>@<groups>,<step_us>": start stagger
         v, st = v.split("@")
         os.environ["DINODET_GEMM_STAGGER"] = st
+    os.environ.pop("DINODET_GEMM_WRES", None)
+    os.environ.pop("DINODET_GEMM_GM", None)
+    if v.startswith("w"):                      # "w": weight-resident tile map of the ping-pong kernels
+        os.environ["DINODET_GEMM_WRES"] = "1"
+        return
+    if v.startswith("g"):                      # "g<N>": m-tiles per group of the time-ordered map
+        os.environ["DINODET_GEMM_GM"] = v[1:]
+        return
     if v.startswith("o"):                      # tile-order A/B: "o0".."o3"
         os.environ["DINODET_GEMM_ORDER"] = v[1:]
         return
