@@ -74,17 +74,29 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16
 // rounding of the result) with one v_rcp and one v_exp instead of libm erff's ~40-instruction body,
 // which made the fc1 epilogue cost ~25 % of that GEMM.  The fp32 (strict) kernels keep erff.
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-  const float erf_abs = fmaf(-p * t, e, 1.0f);
-  const float erf_v = x < 0.f ? -erf_abs : erf_abs;
-  return 0.5f * x * (1.0f + erf_v);
+// Two values per packed instruction (v_pk_fma_f32 / v_pk_mul_f32), rearranged so that no compare / select
+// and no separate log2(e) scaling is left:  z' = |x| sqrt(log2(e) / 2),  t = 1 / (1 + k z'),  gelu(x) = (x + |x|) / 2 - |x| t p(t) / 2 * 2^(-z'^2)
+// -- x * erf(x / sqrt 2) is even in x.  38 VALU instructions per four values instead of 52 (the fc1 epilogue runs alone on its CU).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t x) {
+  f32x2_t ax; ax.x = __builtin_fabsf(x.x); ax.y = __builtin_fabsf(x.y);
+  const f32x2_t z = ax * 0.8493218002880191f;
+  const f32x2_t d = __builtin_elementwise_fma(z, (f32x2_t)(0.2727374808792225f), (f32x2_t)(1.0f));
+  f32x2_t t; t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
+  f32x2_t p = __builtin_elementwise_fma(t, (f32x2_t)(0.5f * 1.061405429f), (f32x2_t)(0.5f * -1.453152027f));
+  p = __builtin_elementwise_fma(p, t, (f32x2_t)(0.5f * 1.421413741f));
+  p = __builtin_elementwise_fma(p, t, (f32x2_t)(0.5f * -0.284496736f));
+  p = __builtin_elementwise_fma(p, t, (f32x2_t)(0.5f * 0.254829592f));
+  const f32x2_t nz2 = -z * z;
+  f32x2_t e; e.x = __builtin_amdgcn_exp2f(nz2.x); e.y = __builtin_amdgcn_exp2f(nz2.y);
+  const f32x2_t q = ax * (t * p);
+  const f32x2_t r = __builtin_elementwise_fma(ax, (f32x2_t)(0.5f), x * 0.5f);
+  return __builtin_elementwise_fma(-q, e, r);
+}
+__device__ __forceinline__ void gelu_fast4(float4& v) {
+  f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+  a = gelu_fast2(a); b = gelu_fast2(b);
+  v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 

@@ -118,7 +118,7 @@ __device__ __forceinline__ void drain_resid(const char* sm, int pitch, const Gem
       if (mm[j] >= M) continue;
       float4 v = *reinterpret_cast<const float4*>(sm + (rb + (it + j) * STEP) * pitch + c4 * 16);
       v.x += cp.bias.x; v.y += cp.bias.y; v.z += cp.bias.z; v.w += cp.bias.w;
-      if (e.act == ACT_GELU) { v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w); }
+      if (e.act == ACT_GELU) { gelu_fast4(v); }
       else if (e.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       v.x = fmaf(v.x, cp.scale.x, r[j].x); v.y = fmaf(v.y, cp.scale.y, r[j].y);
       v.z = fmaf(v.z, cp.scale.z, r[j].z); v.w = fmaf(v.w, cp.scale.w, r[j].w);
@@ -158,7 +158,7 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
       v.x *= sa * cp.wscale.x; v.y *= sa * cp.wscale.y; v.z *= sa * cp.wscale.z; v.w *= sa * cp.wscale.w;
     }
     v.x += cp.bias.x; v.y += cp.bias.y; v.z += cp.bias.z; v.w += cp.bias.w;
-    if (e.act == ACT_GELU) { v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w); }
+    if (e.act == ACT_GELU) { gelu_fast4(v); }
     else if (e.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     v.x *= cp.scale.x; v.y *= cp.scale.y; v.z *= cp.scale.z; v.w *= cp.scale.w;
     size_t orow = (size_t)m;
@@ -243,8 +243,7 @@ __device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, con
     v.x += b0.x; v.y += b0.y; v.z += b0.z; v.w += b0.w;
     u.x += b1.x; u.y += b1.y; u.z += b1.z; u.w += b1.w;
     if (e.act == ACT_GELU) {
-      v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
-      u.x = gelu_fast(u.x); u.y = gelu_fast(u.y); u.z = gelu_fast(u.z); u.w = gelu_fast(u.w);
+      gelu_fast4(v); gelu_fast4(u);
     } else if (e.act == ACT_RELU) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
