@@ -74,22 +74,27 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_new);
     m_run[q] = m_new;
     const float nm = -m_new;
+    float lsum;
     {
       typedef float f32x2_ __attribute__((ext_vector_type(2)));
       const f32x2_ c2 = {c, c}, nm2 = {nm, nm};
+      f32x2_ ls[2] = {{0.f, 0.f}, {0.f, 0.f}};      // row sum on v_pk_add_f32, each exponential pair summed where it is produced
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {   // v_pk_fma_f32: two scores per VALU issue slot
           f32x2_ v = {s[q][kb][r], s[q][kb][r + 1]};
           v = __builtin_elementwise_fma(v, c2, nm2);
-          s[q][kb][r] = __builtin_amdgcn_exp2f(v.x);
-          s[q][kb][r + 1] = __builtin_amdgcn_exp2f(v.y);
+          f32x2_ ev;
+          ev.x = __builtin_amdgcn_exp2f(v.x);
+          ev.y = __builtin_amdgcn_exp2f(v.y);
+          asm("s_nop 0\n\tv_pk_add_f32 %0, %1, %0" : "+v"(ls[kb]) : "v"(ev));     // hipcc splits a C-level packed add next to MFMAs into two v_add_f32; s_nop: the hazard recogniser does not look into inline asm, and a VALU read of a v_exp_f32 result needs one wait state
+          s[q][kb][r] = ev.x;
+          s[q][kb][r + 1] = ev.y;
         }
+      const f32x2_ l2 = ls[0] + ls[1];
+      lsum = l2.x + l2.y;
     }
-    const f32x16 ps = s[q][0] + s[q][1];
-    const float lsum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])) +
-                       (((ps[8] + ps[9]) + (ps[10] + ps[11])) + ((ps[12] + ps[13]) + (ps[14] + ps[15])));
     l_run[q] = fmaf(l_run[q], alpha, lsum);   // per-half partial; the halves are combined once at the end
     // (a thresholded "lazy" rescale behind a wave-uniform branch was measured 4 % SLOWER: the branch splits the
     //  scheduling region; the unconditional 16 packed multiplies are cheaper)

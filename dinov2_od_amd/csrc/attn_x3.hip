@@ -77,6 +77,10 @@ __device__ __forceinline__ void x3_tile(const char* st, const bf16x8 (&qh)[4], c
   const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
   m_run = m_new;
   const float nm = -m_new;
+  // (round 3: the same loop on explicit packed instructions -- v_pk_fma_f32 for the exponent, inline-asm v_pk_add_f32 for the row sum and for
+  //  the residual of the bf16 split -- has 35 fewer VALU instructions per tile, 208 instead of 243, and is 4.5 % SLOWER, 15.2 vs 14.5 ms per
+  //  step: hipcc leaves packed fp32 operations packed only where no MFMA is in flight and splits them elsewhere, and with the matrix pipe 50 %
+  //  busy that choice is the right one here.  attn_bf16.hip, matrix pipe 35 % busy, gains 2.5 % from the packed row sum.)
   float lsum = 0.f;
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
