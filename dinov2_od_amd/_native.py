@@ -128,6 +128,7 @@ SYMBOLS = {
     "dod_reserve_gemm_scratch": (_I, [C.c_size_t]),
     "dod_debug_tail_splits": (C.c_long, []),
     "dod_debug_set_tailsplit": (None, [_I]),
+    "dod_debug_set_dec_fused_split": (None, [_I]),
     "dod_debug_gemm_stamps": (_I, [_P]),
     "dod_debug_pp_stamps": (_I, [_P]),
     "dod_debug_attn_stamps": (_I, [_P]),

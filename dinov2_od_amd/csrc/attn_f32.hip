@@ -115,6 +115,14 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32 a) {
       const float inv = 1.0f / l_run[r];
       if (d0ok) op[lane] = o0[r] * inv;
       if (d1ok) op[lane + 64] = o1[r] * inv;
+      if (a.o3) {        // also as the bf16x3 operand [hi | hi | lo] of the next query-side linear
+        const int Dm = a.heads * dh;
+        bf16_t* o3 = a.o3 + ((size_t)b * a.Lq + q) * 3 * Dm + h * dh;
+        // the empty asm makes y opaque: the fp32 output above is the ROUNDED product, and hipcc (-ffp-contract=fast) would otherwise fold the
+        // multiply into the residual's subtraction, fma(o, inv, -hi), and split a different number than split3 of the stored output does
+        if (d0ok) { float y = o0[r] * inv; asm volatile("" : "+v"(y)); const bf16_t hi = f2bf(y); o3[lane] = hi; o3[Dm + lane] = hi; o3[2 * Dm + lane] = f2bf(y - bf2f(hi)); }
+        if (d1ok) { float y = o1[r] * inv; asm volatile("" : "+v"(y)); const bf16_t hi = f2bf(y); o3[lane + 64] = hi; o3[Dm + lane + 64] = hi; o3[2 * Dm + lane + 64] = f2bf(y - bf2f(hi)); }
+      }
     }
   }
 }

@@ -137,6 +137,27 @@ __global__ __launch_bounds__(256, 2) void attn_f32m_kernel(AttnF32 a) {
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(op + db * 32 + 8 * g + 4 * lh) =
             make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+    if (a.o3) {          // the same values as the bf16x3 operand [hi | hi | lo] of the next query-side linear
+      const int Dm = a.heads * DH;
+      bf16_t* o3 = a.o3 + ((size_t)b * a.Lq + q) * 3 * Dm + h * DH;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          // opaque to the optimiser: split the ROUNDED products the fp32 output holds (hipcc would fold the multiply into the residual's
+          // subtraction as an fma and split a different number than split3 of the stored output does)
+          float y0 = o[db][4 * g] * inv, y1 = o[db][4 * g + 1] * inv, y2 = o[db][4 * g + 2] * inv, y3 = o[db][4 * g + 3] * inv;
+          asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
+          uint2 hi, lo;
+          hi.x = pack2bf(y0, y1); hi.y = pack2bf(y2, y3);
+          lo.x = pack2bf(y0 - __uint_as_float(hi.x << 16), y1 - __uint_as_float(hi.x & 0xffff0000u));
+          lo.y = pack2bf(y2 - __uint_as_float(hi.y << 16), y3 - __uint_as_float(hi.y & 0xffff0000u));
+          bf16_t* d = o3 + db * 32 + 8 * g + 4 * lh;
+          *reinterpret_cast<uint2*>(d) = hi;
+          *reinterpret_cast<uint2*>(d + Dm) = hi;
+          *reinterpret_cast<uint2*>(d + 2 * Dm) = lo;
+        }
+    }
   }
 }
 

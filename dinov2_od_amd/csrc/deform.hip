@@ -17,7 +17,7 @@
 __global__ __launch_bounds__(256) void deform_sample_kernel(const float* __restrict__ proj, int ldp,
                                                             const float* __restrict__ values, int B, int Q, int N,
                                                             int Hd, int P, int dh, int h, int w,
-                                                            float* __restrict__ out, int proj_shared) {
+                                                            float* __restrict__ out, int proj_shared, bf16_t* __restrict__ out3) {
   const int lane = threadIdx.x & 63;
   const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= (long)B * Q * Hd) return;
@@ -74,14 +74,19 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const float* __restr
   float* op = out + (size_t)bq * Dd + hd * dh;
   if (d0ok) op[lane] = acc0;
   if (d1ok) op[lane + 64] = acc1;
+  if (out3) {        // the same values as the bf16x3 operand [hi | hi | lo] of the output projection (K17)
+    bf16_t* o3 = out3 + (size_t)bq * 3 * Dd + hd * dh;
+    if (d0ok) { const bf16_t hi = f2bf(acc0); o3[lane] = hi; o3[Dd + lane] = hi; o3[2 * Dd + lane] = f2bf(acc0 - bf2f(hi)); }
+    if (d1ok) { const bf16_t hi = f2bf(acc1); o3[lane + 64] = hi; o3[Dd + lane + 64] = hi; o3[2 * Dd + lane + 64] = f2bf(acc1 - bf2f(hi)); }
+  }
 }
 
 int launch_deform_sample(const float* proj, int ldp, const float* values, int B, int Q, int N, int Hd, int P, int dh,
-                         int h, int w, float* out, hipStream_t s, int proj_shared) {
+                         int h, int w, float* out, hipStream_t s, int proj_shared, bf16_t* out3) {
   if (P > DF_MAXP || P <= 0 || dh > 128 || dh <= 0) return 2;
   if (h * w != N) return 2;   // the reference raises / re-infers here (deformable_attention.py:76-83)
   const long items = (long)B * Q * Hd;
   hipLaunchKernelGGL(deform_sample_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, proj, ldp, values, B, Q, N,
-                     Hd, P, dh, h, w, out, proj_shared);
+                     Hd, P, dh, h, w, out, proj_shared, out3);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <cstdlib>
 #include <map>
@@ -437,7 +438,15 @@ struct Carver {
   void* take(size_t bytes) { void* p = base ? base + off : nullptr; off += align_up(bytes); return p; }
 };
 
-struct DecWS { float *tgt, *t2, *att, *samp, *qkv, *proj, *ffn, *hb, *qd; void* mem_op; float* values; float* kv; bf16_t* a3; bf16_t* mem2; };   // mem2: bf16x3 mode, memory in the pair layout [M, 2*Dd]
+// -1: DINODET_DEC_FUSED_SPLIT from the environment (default on); 0 / 1: forced (tests)
+static std::atomic<int> g_dec_fused_split{-1};
+extern "C" void dod_debug_set_dec_fused_split(int mode) { g_dec_fused_split.store(mode); }
+// the real carve must fit what the sizing pass (a carve from a null base) reported: a buffer taken only when another POINTER is non-null
+// is invisible to the sizing pass -- fail loudly instead of writing past the caller's workspace
+#define CARVE_FITS(h, c, workspace, wsb)                                                                                      \
+  if ((size_t)((c).base - (char*)(workspace)) + (c).off > (wsb))                                                              \
+    return fail(h, DOD_ERR_STATE, "internal: workspace carve %zu exceeds the %zu bytes provided", (size_t)((c).base - (char*)(workspace)) + (c).off, (size_t)(wsb));
+struct DecWS { float *tgt, *t2, *att, *samp, *qkv, *proj, *ffn, *hb, *qd; void* mem_op; float* values; float* kv; bf16_t* a3; bf16_t* a3b; bf16_t* mem2; };   // mem2: bf16x3 mode, memory in the pair layout [M, 2*Dd]
 struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; float* rs; };   // rs: fp8 mode, per-row activation scales [M]
 
 size_t carve_decoder(const dod_handle* h, Carver& c, int B, int N, DecWS* w, bool need_mem_op) {
@@ -449,7 +458,10 @@ size_t carve_decoder(const dod_handle* h, Carver& c, int B, int N, DecWS* w, boo
   t.proj = (float*)c.take(BQ * (size_t)(h->ncat > 0 ? h->ncat : 4) * 4);
   t.ffn = (float*)c.take(BQ * (size_t)g.dim_feedforward * 4); t.hb = (float*)c.take(BQ * (Dd / 2) * 4);
   t.qd = (float*)c.take(BQ * Dd * 4);
-  { const size_t kmax = Dd > (size_t)g.dim_feedforward ? Dd : (size_t)g.dim_feedforward; t.a3 = (is_bf16(h) || is_x3(h)) ? (bf16_t*)c.take(BQ * 3 * kmax * 2) : nullptr; }
+  { const size_t kmax = Dd > (size_t)g.dim_feedforward ? Dd : (size_t)g.dim_feedforward;
+    const bool want3 = is_bf16(h) || is_x3(h);      // (not "t.a3 != null": the sizing pass carves from a null base)
+    t.a3 = want3 ? (bf16_t*)c.take(BQ * 3 * kmax * 2) : nullptr;
+    t.a3b = want3 ? (bf16_t*)c.take(BQ * 3 * kmax * 2) : nullptr; }     // second operand buffer: a GEMM that reads a3 may write the next GEMM's operand
   t.mem2 = is_x3(h) ? (bf16_t*)c.take(M * 2 * Dd * 2) : nullptr;
   t.mem_op = need_mem_op ? c.take(M * Dd * esz(h)) : nullptr;
   if (g.use_deformable) {
@@ -744,31 +756,62 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
   }
   const float sscale = 1.0f / std::sqrt((float)dh);
   // query-side linear: fp32 MFMA kernel, or (bf16 mode, large enough, N % 4 == 0) the bf16x3-split form on the bf16 kernel
-  auto qlinear = [&](const float* A, int K, const float* Wf, const bf16_t* W3, int rows, int Nout, const GemmEpi& e) -> int {
-    static const int qrows = getenv("DINODET_QSPLIT_ROWS") ? atoi(getenv("DINODET_QSPLIT_ROWS")) : 1024;   // tuning
-    if ((bf || x3) && W3 && ws.a3 && rows >= qrows && Nout >= 128 && Nout % 4 == 0 && e.ldc % 4 == 0 && e.act != ACT_SIGMOID) {
-      KCHK(h, launch_split3(A, K, ws.a3, rows, K, 0, s));
-      return linear(h, true, ws.a3, 3 * K, W3, 3 * K, rows, Nout, 3 * K, e, s, K);
+  static const int qrows = getenv("DINODET_QSPLIT_ROWS") ? atoi(getenv("DINODET_QSPLIT_ROWS")) : 1024;   // tuning
+  // DINODET_DEC_FUSED_SPLIT=0 / dod_debug_set_dec_fused_split(0): every query-side linear splits its own operand with a split3 launch
+  // (the round-2 schedule; A/B and the bit-identity test)
+  static const bool fuse3_env = [] { const char* v = getenv("DINODET_DEC_FUSED_SPLIT"); return !(v && v[0] == '0'); }();
+  const int f3m = g_dec_fused_split.load();
+  const bool fuse3 = f3m < 0 ? fuse3_env : f3m != 0;
+  // will this linear take the split form?  (then its producer writes the [hi | hi | lo] operand itself -- LayerNorm, the attention and
+  // sampling kernels, the ReLU epilogue -- instead of a split3 launch over its fp32 output: 15 launches per forward)
+  auto splits = [&](const bf16_t* W3, int rows, int Nout, int ldc, int act) {
+    return (bf || x3) && W3 && ws.a3 && rows >= qrows && Nout >= 128 && Nout % 4 == 0 && ldc % 4 == 0 && act != ACT_SIGMOID;
+  };
+  // A3: the operand already in the split layout (written by the producer), or null -> split3 of A into ws.a3
+  auto qlinear = [&](const float* A, int K, const float* Wf, const bf16_t* W3, int rows, int Nout, const GemmEpi& e, const bf16_t* A3 = nullptr) -> int {
+    if (splits(W3, rows, Nout, e.ldc, e.act)) {
+      if (!A3) { KCHK(h, launch_split3(A, K, ws.a3, rows, K, 0, s)); A3 = ws.a3; }
+      return linear(h, true, A3, 3 * K, W3, 3 * K, rows, Nout, 3 * K, e, s, K);
     }
     return linear(h, false, A, K, Wf, K, rows, Nout, K, e, s);
   };
+  const bf16_t* tgt3 = nullptr;      // non-null: ws.a3 holds the split form of ws.tgt (written by the LayerNorm that produced it)
   // nb = number of images the query rows are computed for: B, or 1 in layer 0 where tgt = query_embed for every image
   // (detr_decoder.py:59), so the self-attention block and the sampling projections are image-independent there --
   // same kernels, same per-row arithmetic, computed once and broadcast (bit-identical to the per-image evaluation).
   auto self_attn = [&](const DLayer& L, int nb) -> int {                                                       // K11
     const int rows = nb * Q;
-    int r = qlinear(ws.tgt, Dd, L.in_w, L.in_w3, rows, 3 * Dd, epi(L.in_b, ws.qkv, nullptr, 3 * Dd)); if (r) return r;
+    int r = qlinear(ws.tgt, Dd, L.in_w, L.in_w3, rows, 3 * Dd, epi(L.in_b, ws.qkv, nullptr, 3 * Dd), tgt3); if (r) return r;
+    tgt3 = nullptr;
     AttnF32 a; a.q = ws.qkv; a.k = ws.qkv + Dd; a.v = ws.qkv + 2 * Dd; a.o = ws.att; a.ldq = a.ldk = a.ldv = 3 * Dd; a.ldo = Dd;
     a.Lq = a.Lk = Q; a.B = nb; a.heads = Hd; a.dh = dh; a.scale = sscale;
+    const bool o3 = fuse3 && splits(L.out_w3, rows, Dd, Dd, ACT_NONE);
+    if (o3) a.o3 = ws.a3;
     KCHK(h, launch_attn_f32(a, s));
-    r = qlinear(ws.att, Dd, L.out_w, L.out_w3, rows, Dd, epi(L.out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd)); if (r) return r;
-    KCHK(h, launch_layernorm(ws.t2, nullptr, L.n1w, L.n1b, g.dec_ln_eps, rows, Dd, ws.tgt, nullptr, s));
+    r = qlinear(ws.att, Dd, L.out_w, L.out_w3, rows, Dd, epi(L.out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), o3 ? ws.a3 : nullptr); if (r) return r;
+    // dense branch: the next reader of tgt is the cross-attention's query projection
+    const bool n3 = fuse3 && !g.use_deformable && nb == B && splits(L.ca_q_w3, rows, Dd, Dd, ACT_NONE);
+    KCHK(h, launch_layernorm(ws.t2, nullptr, L.n1w, L.n1b, g.dec_ln_eps, rows, Dd, ws.tgt, nullptr, s, nullptr, nullptr, nullptr, 0, n3 ? ws.a3 : nullptr));
+    tgt3 = n3 ? ws.a3 : nullptr;
     return 0;
   };
-  auto ffn = [&](const DLayer& L) -> int {                                                                     // K18
-    int r = qlinear(ws.tgt, Dd, L.l1w, L.l1w3, BQ, Fd, epi(L.l1b, ws.ffn, nullptr, Fd, ACT_RELU)); if (r) return r;
-    r = qlinear(ws.ffn, Fd, L.l2w, L.l2w3, BQ, Dd, epi(L.l2b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd)); if (r) return r;
-    KCHK(h, launch_layernorm(ws.t2, nullptr, L.n3w, L.n3b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
+  auto ffn = [&](const DLayer& L, bool last_layer, const bf16_t* L_next_in_w3) -> int {                         // K18
+    // linear1's ReLU epilogue writes linear2's operand [hi | hi | lo] (GemmEpi::out_split) into the second operand buffer when both take
+    // the split form; the fp32 ffn buffer is then not written at all
+    const bool f3 = fuse3 && splits(L.l1w3, BQ, Fd, Fd, ACT_RELU) && splits(L.l2w3, BQ, Dd, Dd, ACT_NONE) && Fd % 4 == 0;
+    int r;
+    if (f3) {
+      GemmEpi e1 = epi(L.l1b, nullptr, nullptr, 3 * Fd, ACT_RELU);
+      e1.out_bf16 = ws.a3b; e1.out_split = Fd;
+      r = qlinear(ws.tgt, Dd, L.l1w, L.l1w3, BQ, Fd, e1, tgt3);
+    } else r = qlinear(ws.tgt, Dd, L.l1w, L.l1w3, BQ, Fd, epi(L.l1b, ws.ffn, nullptr, Fd, ACT_RELU), tgt3);
+    if (r) return r;
+    tgt3 = nullptr;
+    r = qlinear(ws.ffn, Fd, L.l2w, L.l2w3, BQ, Dd, epi(L.l2b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), f3 ? ws.a3b : nullptr); if (r) return r;
+    // the next split reader of tgt: the next layer's self-attention input projection (all B images from layer 1 on), or the box head
+    const bool n3 = fuse3 && (last_layer ? splits(h->bb0_w3, BQ, Dd / 2, Dd / 2, ACT_RELU) : splits(L_next_in_w3, BQ, 3 * Dd, 3 * Dd, ACT_NONE));
+    KCHK(h, launch_layernorm(ws.t2, nullptr, L.n3w, L.n3b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s, nullptr, nullptr, nullptr, 0, n3 ? ws.a3 : nullptr));
+    tgt3 = n3 ? ws.a3 : nullptr;
     return 0;
   };
   int uniq_idx[64]; { int u = 0; for (int j = 0; j < g.dec_layers && j < 64; ++j) uniq_idx[j] = h->DL[j].vp_alias < 0 ? u++ : -1; }
@@ -782,28 +825,36 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
       if (shared0) KCHK(h, launch_bcast_rows(ws.tgt, ws.tgt + (size_t)Q * Dd, B - 1, Q, Dd, s));   // rows of image 0 -> images 1..B-1
       const int src = L.vp_alias >= 0 ? L.vp_alias : j;
       const float* vals = ws.values + (size_t)uniq_idx[src] * M * Dd;
-      KCHK(h, launch_deform_sample(ws.proj, h->ncat, vals, B, Q, N, Hd, Pn, dh, fh, fw, ws.samp, s, shared0 ? 1 : 0));
-      rc = qlinear(ws.samp, Dd, L.op_w, L.op_w3, BQ, Dd, epi(L.op_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd)); if (rc) return rc;   // K17
-      KCHK(h, launch_layernorm(ws.t2, nullptr, L.n2w, L.n2b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
+      const bool s3 = fuse3 && splits(L.op_w3, BQ, Dd, Dd, ACT_NONE);
+      KCHK(h, launch_deform_sample(ws.proj, h->ncat, vals, B, Q, N, Hd, Pn, dh, fh, fw, ws.samp, s, shared0 ? 1 : 0, s3 ? ws.a3 : nullptr));
+      rc = qlinear(ws.samp, Dd, L.op_w, L.op_w3, BQ, Dd, epi(L.op_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s3 ? ws.a3 : nullptr); if (rc) return rc;   // K17
+      const bool n3 = fuse3 && splits(L.l1w3, BQ, Fd, Fd, ACT_RELU);      // next reader of tgt: linear1
+      KCHK(h, launch_layernorm(ws.t2, nullptr, L.n2w, L.n2b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s, nullptr, nullptr, nullptr, 0, n3 ? ws.a3 : nullptr));
+      tgt3 = n3 ? ws.a3 : nullptr;
     } else {
       // K20: dense cross-attention over all N memory tokens
       if (shared0) KCHK(h, launch_bcast_rows(ws.tgt, ws.tgt + (size_t)Q * Dd, B - 1, Q, Dd, s));
-      rc = qlinear(ws.tgt, Dd, L.ca_q_w, L.ca_q_w3, BQ, Dd, epi(L.ca_q_b, ws.qd, nullptr, Dd)); if (rc) return rc;
+      rc = qlinear(ws.tgt, Dd, L.ca_q_w, L.ca_q_w3, BQ, Dd, epi(L.ca_q_b, ws.qd, nullptr, Dd), tgt3); if (rc) return rc;
+      tgt3 = nullptr;
       if (x3 && L.ca_kv_w2) rc = linear3(h, ws.mem2, L.ca_kv_w2, M, 2 * Dd, Dd, epi(L.ca_kv_b, ws.kv, nullptr, 2 * Dd), s);
       else rc = linear(h, bf, mem_op, Dd, L.ca_kv_w, Dd, M, 2 * Dd, Dd, epi(L.ca_kv_b, ws.kv, nullptr, 2 * Dd), s);
       if (rc) return rc;
       AttnF32 a; a.q = ws.qd; a.k = ws.kv; a.v = ws.kv + Dd; a.o = ws.att; a.ldq = Dd; a.ldk = a.ldv = 2 * Dd; a.ldo = Dd;
       a.Lq = Q; a.Lk = N; a.B = B; a.heads = Hd; a.dh = dh; a.scale = sscale;
+      const bool o3 = fuse3 && splits(L.ca_out_w3, BQ, Dd, Dd, ACT_NONE);
+      if (o3) a.o3 = ws.a3;
       KCHK(h, launch_attn_f32(a, s));
-      rc = qlinear(ws.att, Dd, L.ca_out_w, L.ca_out_w3, BQ, Dd, epi(L.ca_out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd)); if (rc) return rc;
-      KCHK(h, launch_layernorm(ws.t2, nullptr, L.n2w, L.n2b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s));
+      rc = qlinear(ws.att, Dd, L.ca_out_w, L.ca_out_w3, BQ, Dd, epi(L.ca_out_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), o3 ? ws.a3 : nullptr); if (rc) return rc;
+      const bool n3 = fuse3 && splits(L.l1w3, BQ, Fd, Fd, ACT_RELU);
+      KCHK(h, launch_layernorm(ws.t2, nullptr, L.n2w, L.n2b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s, nullptr, nullptr, nullptr, 0, n3 ? ws.a3 : nullptr));
+      tgt3 = n3 ? ws.a3 : nullptr;
     }
-    rc = ffn(L); if (rc) return rc;
+    rc = ffn(L, j + 1 == g.dec_layers, j + 1 < g.dec_layers ? h->DL[j + 1].in_w3 : nullptr); if (rc) return rc;
     tap(h, 3000 + j, ws.tgt, false, (size_t)BQ * Dd, s);
   }
   // K19 heads -> packed [B, Q, C+4]
   rc = linear(h, false, ws.tgt, Dd, h->cls_w, Dd, BQ, C, Dd, epi(h->cls_b, det, nullptr, C + 4), s); if (rc) return rc;
-  rc = qlinear(ws.tgt, Dd, h->bb0_w, h->bb0_w3, BQ, Dd / 2, epi(h->bb0_b, ws.hb, nullptr, Dd / 2, ACT_RELU)); if (rc) return rc;
+  rc = qlinear(ws.tgt, Dd, h->bb0_w, h->bb0_w3, BQ, Dd / 2, epi(h->bb0_b, ws.hb, nullptr, Dd / 2, ACT_RELU), tgt3); if (rc) return rc;
   rc = linear(h, false, ws.hb, Dd / 2, h->bb2_w, Dd / 2, BQ, 4, Dd / 2, epi(h->bb2_b, det + C, nullptr, C + 4, ACT_SIGMOID), s); if (rc) return rc;
   return DOD_OK;
 }
@@ -965,6 +1016,7 @@ int dod_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* 
     BbWS bw; DecWS dw;
     carve_backbone(h, c, B, N, &bw);
     carve_decoder(h, c, B, N, &dw, false);
+    CARVE_FITS(h, c, workspace, wsb)
     rc = backbone_impl(h, pixels, B, H, W, bw, nullptr, true, s); if (rc) return rc;
     return decoder_impl(h, bw.mem, B, N, dw, det, s);
   }
@@ -980,6 +1032,7 @@ int dod_forward(dod_handle* h, const float* pixels, int B, int H, int W, float* 
     BbWS bw; DecWS dw;
     carve_backbone(h, c, Bh[i], N, &bw);
     carve_decoder(h, c, Bh[i], N, &dw, false);
+    CARVE_FITS(h, c, workspace, wsb)
     HIPCHK(h, hipStreamWaitEvent(h->side[i], h->fork_ev, 0));
     rc = backbone_impl(h, pixels + (size_t)b0 * 3 * H * W, Bh[i], H, W, bw, nullptr, true, h->side[i]); if (rc) return rc;
     rc = decoder_impl(h, bw.mem, Bh[i], N, dw, det + (size_t)b0 * det_stride, h->side[i]); if (rc) return rc;
@@ -1000,6 +1053,7 @@ int dod_forward_u8(dod_handle* h, const uint8_t* pixels_hwc, int B, int H, int W
   BbWS bw; DecWS dw;
   carve_backbone(h, c, B, N, &bw);
   carve_decoder(h, c, B, N, &dw, false);
+  CARVE_FITS(h, c, workspace, wsb)
   rc = backbone_impl(h, nullptr, B, H, W, bw, nullptr, true, (hipStream_t)stream, -1, nullptr, pixels_hwc); if (rc) return rc;
   return decoder_impl(h, bw.mem, B, N, dw, det, (hipStream_t)stream);
 }
@@ -1013,6 +1067,7 @@ int dod_backbone_forward(dod_handle* h, const float* pixels, int B, int H, int W
   Carver c(align_ws(workspace));
   BbWS bw;
   carve_backbone(h, c, B, N, &bw);
+  CARVE_FITS(h, c, workspace, wsb)
   return backbone_impl(h, pixels, B, H, W, bw, features, false, (hipStream_t)stream);
 }
 
@@ -1026,6 +1081,7 @@ int dod_backbone_prefix(dod_handle* h, const float* pixels, int B, int H, int W,
   Carver c(align_ws(workspace));
   BbWS bw;
   carve_backbone(h, c, B, N, &bw);
+  CARVE_FITS(h, c, workspace, wsb)
   return backbone_impl(h, pixels, B, H, W, bw, nullptr, false, (hipStream_t)stream, nblocks, x_out);
 }
 
@@ -1038,6 +1094,7 @@ int dod_decoder_forward(dod_handle* h, const float* memory, int B, int N, float*
   Carver c(align_ws(workspace));
   DecWS dw;
   carve_decoder(h, c, B, N, &dw, true);
+  CARVE_FITS(h, c, workspace, wsb)
   hipStream_t s = (hipStream_t)stream;
   const void* mem_op = memory;
   if (is_bf16(h)) {

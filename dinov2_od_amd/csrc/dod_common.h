@@ -174,7 +174,8 @@ int launch_quant_rows_fp8(const void* x, int in_bf16, int ld, int rows, int cols
 // h2: out_split3 is written in the H2 operand format (row pitch 4*D bytes) instead
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s,
-                     unsigned char* out_fp8 = nullptr, float* out_scale = nullptr, bf16_t* out_split3 = nullptr, int h2 = 0);
+                     unsigned char* out_fp8 = nullptr, float* out_scale = nullptr, bf16_t* out_split3 = nullptr, int h2 = 0,
+                     bf16_t* out_a3 = nullptr);      // out_a3 (with out_f32 only): also the bf16x3 activation layout [hi | hi | lo], row pitch 3*D
 
 // backbone attention, bf16 MFMA flash kernel, head_dim 64.  qkv [B*N, 3*D] bf16 -> ctx [B*N, D] bf16
 int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s);
@@ -186,6 +187,8 @@ struct AttnF32 {
   int Lq, Lk;                 // rows per batch item
   int B, heads, dh;
   float scale;
+  bf16_t* o3 = nullptr;       // optional: the output also as a bf16x3 activation operand [hi | hi | lo] of heads*dh columns each (row pitch
+                              // 3*heads*dh), what the decoder's next query-side linear reads -- saves its split3 launch
   float* lse = nullptr;       // optional [B, heads, Lq, 2]: (max_j(s c), sum_j 2^(s c - max)) of every score row, c = scale log2(e) -- what
                               // the flash-style adjoint (launch_attn_f32_bwd) recomputes the probabilities from; MFMA kernel only
 };
@@ -254,4 +257,4 @@ int launch_bcast_rows(const float* src, float* dst, int B, int rows, int D, hipS
 
 // K12/K13/K15: proj [B*Q, ldp] = [ref logits(2) | offsets(Hd*P*2) | weight logits(Hd*P)], values fp32 [B*N, Dd]
 int launch_deform_sample(const float* proj, int ldp, const float* values, int B, int Q, int N, int Hd, int P, int dh,
-                         int h, int w, float* out, hipStream_t s, int proj_shared = 0);
+                         int h, int w, float* out, hipStream_t s, int proj_shared = 0, bf16_t* out3 = nullptr);   // out3: also [hi | hi | lo], pitch 3*Hd*dh

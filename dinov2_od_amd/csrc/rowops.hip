@@ -11,8 +11,8 @@
 #define LN_MAXC 8
 // Output forms (compile-time: the round-2 kernel took them as runtime pointers / an int and carried every writer's registers -- 100
 // VGPRs, four waves per SIMD -- which cost 27 % of its bandwidth).
-enum { LN_F32 = 1, LN_BF16 = 2, LN_PAIR = 4, LN_H2 = 8, LN_FP8 = 16 };
-struct LnOut { float* f32; bf16_t* bf16; unsigned char* fp8; float* scale; bf16_t* split; };
+enum { LN_F32 = 1, LN_BF16 = 2, LN_PAIR = 4, LN_H2 = 8, LN_FP8 = 16, LN_S3 = 32 };
+struct LnOut { float* f32; bf16_t* bf16; unsigned char* fp8; float* scale; bf16_t* split; bf16_t* a3; };
 // NCH float4 chunks per lane (compile-time trip count: D = 768 holds a row in 3 x 4 registers instead of LN_MAXC x 4); EXACT: D == 256 NCH
 template <int NCH, bool EXACT, int OUT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
@@ -109,6 +109,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         reinterpret_cast<uint2*>(ob)[c] = hi;
         reinterpret_cast<uint2*>(ob + D)[c] = lo;
       }
+      if (OUT & LN_S3) {     // bf16x3 activation operand [hi | hi | lo] (row pitch 3*D) of the decoder's query-side linears: saves their split3 launch
+        uint2 hi, lo;
+        hi.x = pack2bf(w.x, w.y);
+        hi.y = pack2bf(w.z, w.w);
+        lo.x = pack2bf(w.x - __uint_as_float(hi.x << 16), w.y - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = pack2bf(w.z - __uint_as_float(hi.y << 16), w.w - __uint_as_float(hi.y & 0xffff0000u));
+        bf16_t* ob = o.a3 + (size_t)row * 3 * D;
+        reinterpret_cast<uint2*>(ob)[c] = hi;
+        reinterpret_cast<uint2*>(ob + D)[c] = hi;
+        reinterpret_cast<uint2*>(ob + 2 * D)[c] = lo;
+      }
       if (OUT & LN_BF16) {
         uint2 p;
         p.x = pack2bf(w.x, w.y);
@@ -145,13 +156,16 @@ static void ln_dispatch(const float* x, const float* add, const float* gamma, co
 
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s, unsigned char* out_fp8,
-                     float* out_scale, bf16_t* out_split3, int h2) {
+                     float* out_scale, bf16_t* out_split3, int h2, bf16_t* out_a3) {
   if (rows <= 0) return 1;
   if (D % 4 != 0 || D > 256 * LN_MAXC) return 2;
   if (h2 && (!out_split3 || D % 32 != 0)) return 2;
   if ((out_fp8 == nullptr) != (out_scale == nullptr)) return 2;
-  LnOut o{out_f32, out_bf16, out_fp8, out_scale, out_split3};
-  if (out_fp8) ln_dispatch<LN_FP8>(x, add, gamma, beta, eps, rows, D, o, s);
+  LnOut o{out_f32, out_bf16, out_fp8, out_scale, out_split3, out_a3};
+  if (out_a3) {
+    if (!out_f32 || out_bf16 || out_fp8 || out_split3) return 2;
+    ln_dispatch<LN_F32 | LN_S3>(x, add, gamma, beta, eps, rows, D, o, s);
+  } else if (out_fp8) ln_dispatch<LN_FP8>(x, add, gamma, beta, eps, rows, D, o, s);
   else if (out_split3 && (out_f32 || out_bf16)) return 2;
   else if (out_split3) { if (h2) ln_dispatch<LN_H2>(x, add, gamma, beta, eps, rows, D, o, s); else ln_dispatch<LN_PAIR>(x, add, gamma, beta, eps, rows, D, o, s); }
   else if (out_f32 && out_bf16) ln_dispatch<LN_F32 | LN_BF16>(x, add, gamma, beta, eps, rows, D, o, s);

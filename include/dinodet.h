@@ -353,6 +353,10 @@ long dod_debug_tail_splits(void);   /* number of GEMM calls that took the tail-s
 /* mode of the tail split: -1 the DINODET_GEMM_TAILSPLIT environment default (the shipped heuristic when unset), 0 off, 1 heuristic,
  * 2 every qualifying shape (tests force it for their own cases and hand -1 back) */
 void dod_debug_set_tailsplit(int mode);
+/* decoder schedule: 1 = the producers of the query-side linears' operands (LayerNorm, the fp32 attention and sampling kernels, linear1's ReLU
+ * epilogue) write the bf16x3 operand themselves, 0 = a split3 launch per linear (the round-2 schedule), -1 = DINODET_DEC_FUSED_SPLIT from
+ * the environment (default 1).  Both schedules produce the same bits (tests/test_gpu_forward.py). */
+void dod_debug_set_dec_fused_split(int mode);
 int dod_debug_gemm_stamps(void* dev_buf);
 /* same for the ping-pong kernels (gemm_pp.hip): 8 x uint64 per workgroup, shader cycles (tools/pp_timeline.py) */
 int dod_debug_pp_stamps(void* dev_buf);

@@ -434,6 +434,39 @@ def test_bf16_decoder_split3_linears_large_batch(G):
     assert rel_err(outs["bf16"]["pred_logits"].cpu().numpy(), outs["fp32"]["pred_logits"].cpu().numpy()) < 3e-2
 
 
+@pytest.mark.parametrize("deform,Hd", [(True, 4), (False, 4), (False, 2)])       # head_dim 64: fp32-MFMA attention kernel; 128: the VALU one
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_decoder_fused_operand_split_is_bit_identical(G, deform, Hd, precision):
+    """The producers of the query-side linears' operands (LayerNorm, the fp32 attention / sampling kernels, linear1's ReLU epilogue) write
+    the bf16x3 operand [hi | hi | lo] themselves instead of a split3 launch per linear: same roundings, so the same bits -- both decoder
+    branches, the box head's reader of the last LayerNorm included (B*Q >= 1024 rows take the split form)."""
+    from dinov2_od_amd import _native as nat
+    from dinov2_od_amd.models import DETRDecoder
+    B, Q, Dd, N = 11, 100, 256, 257
+    dc = cases.dec_cfg(deform, Dd, Hd, Q)
+    sd = synth.decoder_state_dict(dc, seed=5, prefix="decoder.")
+    mem = synth.normal(3, "memory.fused3", (B, N, Dd), 1.0)
+    m = DETRDecoder(Q, Dd, Hd, dc.num_layers, dc.num_classes, dim_feedforward=dc.dim_feedforward, n_points=dc.n_points,
+                    use_deformable=deform, precision=precision)
+    G.load_np_state(m, {k[len("decoder."):]: v for k, v in sd.items()})
+    m = m.to(G.dev()).eval()
+    outs = {}
+    try:
+        for mode in (0, 1):
+            nat.lib().dod_debug_set_dec_fused_split(mode)
+            o = m(G.to_gpu(mem))
+            G.sync()
+            outs[mode] = {k: v.cpu().numpy().copy() for k, v in o.items()}
+    finally:
+        nat.lib().dod_debug_set_dec_fused_split(-1)
+    for k in ("pred_logits", "pred_boxes"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    want_l, want_b = orc.decoder_forward(sd, dc, torch.from_numpy(mem).to(torch.bfloat16).float() if precision == "bf16" else torch.from_numpy(mem),
+                                         emulate_bf16=precision == "bf16")
+    assert rel_err(outs[1]["pred_logits"], want_l.numpy()) < (5e-3 if precision == "bf16" else TOL)
+    assert rel_err(outs[1]["pred_boxes"], want_b.numpy()) < (5e-3 if precision == "bf16" else TOL)
+
+
 @pytest.mark.parametrize("variant", ["large", "giant"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x2", "bf16"])
 def test_large_and_giant_shaped_models_two_blocks(G, variant, precision):
