@@ -948,7 +948,8 @@ int dod_reserve_gemm_scratch(size_t bytes) { return gemm_tail_reserve(bytes) ? f
 
 int dod_finalize_weights(dod_handle* h, void* stream) {
   if (!h) return fail(nullptr, DOD_ERR_INVALID, "null handle");
-  (void)gemm_tail_reserve((size_t)64 << 20);     // K-split scratch of the GEMMs' wave-quantisation tail (gemm_pp.hip): never allocated inside a forward
+  { static const size_t mb = [] { const char* v = getenv("DINODET_GEMM_SCRATCH_MB"); return v && atoi(v) > 0 ? (size_t)atoi(v) : (size_t)64; }();
+    (void)gemm_tail_reserve(mb << 20); }     // K-split scratch of the GEMMs' wave-quantisation tail (gemm_pp.hip): never allocated inside a forward
   return finalize_impl(h, (hipStream_t)stream);
 }
 

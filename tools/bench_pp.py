@@ -56,7 +56,7 @@ def main():
     variants = a.variants.split(";") if ";" in a.variants else a.variants.split(",")
     if a.orders:
         variants = ["o" + o for o in a.orders.split(",")]
-    L = nat.lib(); L.dod_reserve_gemm_scratch(64 << 20)
+    L = nat.lib(); L.dod_reserve_gemm_scratch(int(os.environ.get("DINODET_GEMM_SCRATCH_MB", "64")) << 20)
     dev = torch.device("cuda:0")
     M, D = a.rows or a.batch * 1370, a.hidden
     g = torch.Generator(device="cpu").manual_seed(0)
