@@ -525,6 +525,16 @@ def worker(a):
                         res["also"][f"vitb224_{prec}"] = {"error": f"{type(e).__name__}: {e}"}
                 del x2
                 torch.cuda.empty_cache()
+                # BASELINE configs[2] as written shards its 64 images over 8 GPUs: the 8-image shard on this GPU (the headline runs the whole
+                # batch of 64 per GPU -- weak scaling; an 8-GPU run of the literal configuration moves at 8 x this figure less the all-gather)
+                for prec in ("bf16", "bf16x3"):
+                    try:
+                        r8 = measure_mode(name, Q, R, prec, x[:8].contiguous(), max(10, a.steps // 2), max(3, a.warmup // 2), device, use_graph)
+                        r8["workload"] = "ViT-B/14 518x518, 100 queries, batch 8 (the per-GPU shard of BASELINE configs[2] as written)"
+                        res["also"][f"vitb518_shard8_{prec}"] = r8
+                    except Exception as e:
+                        res["also"][f"vitb518_shard8_{prec}"] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
                 # BASELINE configs[3] and configs[4] on their per-GPU shards (16 / 32 images), a few timed steps each: the driver-visible
                 # number for the ViT-L bf16 and the ViT-g fp8-MFMA configurations (parity: tests/test_gpu_bench_shapes.py runs these
                 # very batches against the reference's G7 / G8 goldens)
