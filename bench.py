@@ -536,7 +536,7 @@ def worker(a):
                         res["also"][f"vitb518_shard8_{prec}"] = {"error": f"{type(e).__name__}: {e}"}
                 torch.cuda.empty_cache()
                 # BASELINE configs[3] and configs[4] on their per-GPU shards (16 / 32 images), a few timed steps each: the driver-visible
-                # number for the ViT-L bf16 and the ViT-g fp8-MFMA configurations (parity: tests/test_gpu_bench_shapes.py runs these
+                # number for the ViT-L bf16 and the ViT-g fp8-MFMA configurations (parity: tests/test_gpu_timed_shapes.py runs these
                 # very batches against the reference's G7 / G8 goldens)
                 for wl, prec in (("vitl518", "bf16"), ("vitg518", "fp8")):
                     try:
