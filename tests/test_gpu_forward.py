@@ -568,8 +568,9 @@ def _full_run(G, variant, precision):
     return res, blocks, cases.golden(name)
 
 
-@pytest.mark.parametrize("precision", GATED)
-@pytest.mark.parametrize("variant", ["large", "giant"])       # the lower decorator varies slowest: one state dict per variant
+# (giant x fp16x2 at full depth is left to the two-block test above and to ViT-L at full depth: the -m gpu suite has a 900 s limit on the
+#  driver's box and the 40-block model costs 12-20 s per mode)
+@pytest.mark.parametrize("variant,precision", [("large", "fp32"), ("large", "bf16x3"), ("large", "fp16x2"), ("giant", "fp32"), ("giant", "bf16x3")])
 def test_full_depth_configs_gated_vs_reference(G, variant, precision):
     """configs[3] ViT-L/14 and configs[4] ViT-g/14 (SwiGLU, 40 blocks) at 518x518 with 300 queries, ALL blocks, one image:
     both parity-gated modes against the REFERENCE's own forward (G7 / G8: modeling_dinov2.py:300-314 at depth, the 1024 /
@@ -590,7 +591,7 @@ def test_full_depth_configs_gated_vs_reference(G, variant, precision):
         assert e < TOL, (k, e)
 
 
-@pytest.mark.parametrize("variant,precision", [("giant", "bf16"), ("giant", "fp8"), ("large", "bf16")])   # giant is resident from the test above
+@pytest.mark.parametrize("variant,precision", [("giant", "fp8"), ("large", "bf16")])   # giant is resident from the test above; each in the mode BASELINE quotes it in
 def test_full_depth_configs_throughput_modes(G, variant, precision):
     """The same two configurations in the opt-in throughput modes (configs[3] is quoted in bf16, configs[4] in fp8), full depth.
     Held (a) stage by stage to the oracle evaluated with the SAME operand rounding (tests/golden/emu_*.npz, generated by
@@ -615,6 +616,9 @@ def test_full_depth_configs_throughput_modes(G, variant, precision):
         assert np.isfinite(r[k]).all() and got < K * floor, (k, got, floor)
 
 
+_SWEEP_ORACLE = {}
+
+
 @pytest.mark.parametrize("precision", GATED)
 def test_reference_point_conditioning_sweep(G, precision):
     """The synthetic reference_points_proj weight uses sigma = 0.01 so that the fp32 noise floor on the logits leaves a margin
@@ -632,8 +636,9 @@ def test_reference_point_conditioning_sweep(G, precision):
         G.load_np_state(m, sd)
         out = m(G.to_gpu(x))
         G.sync()
-        exact = orc.detector_forward(sd, bb, dc, x, dtype=torch.float64)
-        f32 = orc.detector_forward(sd, bb, dc, x)
+        if sigma not in _SWEEP_ORACLE:                   # the two CPU evaluations do not depend on the mode: once per sigma
+            _SWEEP_ORACLE[sigma] = (orc.detector_forward(sd, bb, dc, x, dtype=torch.float64), orc.detector_forward(sd, bb, dc, x))
+        exact, f32 = _SWEEP_ORACLE[sigma]
         for k in ("pred_logits", "pred_boxes"):
             got = rel_err(out[k].cpu().numpy(), exact[k].numpy())
             floor = rel_err(f32[k].numpy(), exact[k].numpy())
