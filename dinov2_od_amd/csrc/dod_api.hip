@@ -1164,6 +1164,22 @@ int dod_op_linear_fp8(const void* A, int lda, const float* a_scale, const void* 
   if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear_fp8 rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
   return DOD_OK;
 }
+int dod_op_linear_fp8_mx(const void* A, int lda, const void* a_block_scales, const void* W, int ldw, const float* w_scale, int M, int N, int K,
+                         const float* bias, const float* scale, const float* resid, int ldr, void* out, int out_dtype, int ldc, int act,
+                         void* stream) {
+  if (!A || !W || !out || !a_block_scales || !w_scale) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  GemmEpi e = epi(bias, out_dtype == DOD_F32 ? (float*)out : nullptr, out_dtype == DOD_BF16 ? out : nullptr, ldc, act, scale, resid, ldr);
+  e.a_bs = (const unsigned char*)a_block_scales; e.w_scale = w_scale;
+  int r = launch_gemm_fp8((const unsigned char*)A, lda, (const unsigned char*)W, ldw, M, N, K, e, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear_fp8_mx rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
+  return DOD_OK;
+}
+int dod_op_quant_mx_fp8(const void* x, int in_dtype, int ld, int rows, int cols, void* q, int ldq, void* block_scales, void* stream) {
+  if (!x || !q || !block_scales) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  int r = launch_quant_mx_fp8(x, in_dtype == DOD_BF16, ld, rows, cols, (unsigned char*)q, ldq, (unsigned char*)block_scales, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_quant_mx_fp8 rejected rows=%d cols=%d", rows, cols);
+  return DOD_OK;
+}
 int dod_op_split_pair(const float* x, int ld, int rows, int cols, void* out, void* stream) {
   if (!x || !out) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
   return launch_split2(x, ld, (bf16_t*)out, rows, cols, (hipStream_t)stream) ? fail(nullptr, DOD_ERR_HIP, "launch failed") : DOD_OK;

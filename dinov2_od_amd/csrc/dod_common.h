@@ -41,6 +41,17 @@ __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d
   w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
   return (unsigned)w;
 }
+// ---- block-scaled ("MX") e4m3 activations of the fp8 GEMM (gemm_fp8.hip gemm_fp8mx_256x128_kernel): one e8m0 byte per 32 elements along K,
+// value 2^(byte - 127), the smallest power of two with amax_block / 448 <= 2^e (no element saturates); a zero block gets byte 1.
+// Scale bytes [rows][2][K / 64]: block bi of a row (K-tile bi >> 1, half bi & 1) at byte (bi & 1) * (K / 64) + (bi >> 1) of its K / 32 bytes.
+__device__ __forceinline__ unsigned mx_ebyte(float amax) {
+  const unsigned b = __float_as_uint(amax * (1.0f / 448.0f));
+  unsigned eb = ((b >> 23) & 0xffu) + ((b & 0x7fffffu) ? 1u : 0u);
+  eb = eb < 1u ? 1u : (eb > 253u ? 253u : eb);
+  return eb;
+}
+__device__ __forceinline__ float mx_inv_scale(unsigned eb) { return __uint_as_float((254u - eb) << 23); }      // 2^-(eb - 127)
+__device__ __forceinline__ size_t mx_scale_off(int K, int bi) { return (size_t)(bi & 1) * (K >> 6) + (bi >> 1); }
 // ---- "H2" operand format (fp16 main product + e4m3 compensation terms; gemm_pp.hip gemm_h2_256x256_kernel, the fp16x2 precision mode)
 // x = h + l with h = fp16(x) (11 significant bits) and l = x - h (|l| <= 2^-11 |x|).  x.w ~ hx hw + [hx lw + lx hw]: the main product
 // on the fp16 MFMA, the two cross terms -- which only need ~4 significant bits to sit below 2^-16 of the result -- as ONE
@@ -122,6 +133,7 @@ struct GemmEpi {
                           // < 0 pair layout [hi | lo], each -out_split wide (ldc = -2*out_split)
   const float* a_scale;   // fp8 GEMM only: per-row (token) dequant scale of A, [M]; null otherwise
   const float* w_scale;   // fp8 GEMM only: per-output-feature dequant scale of W, [N]
+  const unsigned char* a_bs;   // fp8 GEMM only: e8m0 BLOCK scales of A (one byte per 32 elements along K, layout [M][2][K / 64]: gemm_fp8.hip) instead of a_scale
   int out_h2;             // with out_bf16: H2 activation rows (above) of N columns at row pitch ldc (2-byte units, >= 2N)
   const unsigned char* h2_wexp;   // H2 GEMM only: E8M0 byte (127 - e) of every weight row's e4m3 scale 2^e, [N]
   int ksplit;             // ping-pong / H2 kernels only: > 1 = the grid's y index is a K slice of kslice_len k; the slice's fp32 partial
@@ -156,6 +168,8 @@ struct GemmF32X {
 };
 int launch_gemm_f32x(const GemmF32X& g, hipStream_t s);
 // fp8 (OCP e4m3) operands, one byte per element, K contiguous; e.a_scale / e.w_scale are the dequant scales
+// (e.a_bs instead of e.a_scale: block-scaled activations, K % 256 == 0)
+int launch_quant_mx_fp8(const void* x, int in_bf16, int ld, int rows, int cols, unsigned char* q, int ldq, unsigned char* bs, hipStream_t s);
 int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int ldw, int M, int N, int K,
                     const GemmEpi& e, hipStream_t s);
 // rows x cols fp32 or bf16 -> e4m3 with one scale per row: scale[r] = amax_r / 448 (1 if the row is all zero),

@@ -136,7 +136,7 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
   const int c4 = tid % C4;
   const int n = n0 + 4 * c4;
   if (n >= N) return;
-  if (e.resid && e.out_f32 && e.rows_per_img == 0 && !e.a_scale) {
+  if (e.resid && e.out_f32 && e.rows_per_img == 0 && !e.a_scale && !e.a_bs) {
     // The in-place fp32 residual epilogue (out-proj, fc2): a thread visits ROWS / (NT / C4) rows, and with one residual load in flight
     // per thread the pass is a chain of memory latencies (tools/pp_timeline.py: 63 k cycles per 256x256 tile, 15 GB/s per CU).
     // Rows go in batches of RB: RB residual loads are issued before the first of them is consumed.  (Unrolling the whole generic loop
@@ -153,8 +153,8 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
     const int m = rowmap(row_l);
     if (m >= M) continue;
     float4 v = *reinterpret_cast<const float4*>(sm + row_l * pitch + c4 * 16);
-    if (e.a_scale) {   // fp8 operands: (A_q W_q^T)[m][n] * a_scale[m] * w_scale[n]
-      const float sa = e.a_scale[m];
+    if (e.a_scale || e.a_bs) {   // fp8 operands: (A_q W_q^T)[m][n] * a_scale[m] * w_scale[n]  (block-scaled A: its scales went into the MFMAs)
+      const float sa = e.a_scale ? e.a_scale[m] : 1.0f;
       v.x *= sa * cp.wscale.x; v.y *= sa * cp.wscale.y; v.z *= sa * cp.wscale.z; v.w *= sa * cp.wscale.w;
     }
     v.x += cp.bias.x; v.y += cp.bias.y; v.z += cp.bias.z; v.w += cp.bias.w;
@@ -221,7 +221,7 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
 // and row instead of two 8-byte ones: the store tail of a tile is bound by the number of store instructions, not by their bytes
 // (guide T21), and a workgroup per CU has nothing else to overlap it with.
 __device__ __forceinline__ bool drain8_ok(const GemmEpi& e, int N) {
-  return e.out_bf16 && e.out_split <= 0 && !e.resid && e.rows_per_img == 0 && !e.a_scale && (N & 7) == 0 && (e.ldc & 7) == 0 &&
+  return e.out_bf16 && e.out_split <= 0 && !e.resid && e.rows_per_img == 0 && !e.a_scale && !e.a_bs && (N & 7) == 0 && (e.ldc & 7) == 0 &&
          (e.out_split == 0 || ((-e.out_split) & 7) == 0);
 }
 template <int ROWS, int COLS, int NT, typename RowMap>

@@ -13,6 +13,7 @@
 #include "dod_common.h"
 #include "gemm_epi.h"
 #include <cstdlib>
+#include <type_traits>
 
 #define F8M 256
 #define F8N 128
@@ -133,6 +134,156 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8_256x128_kernel(const unsigned
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same kernel with BLOCK-SCALED activations (MX style): A carries one e8m0 byte per 32 elements along K (value 2^(byte - 127)) instead
+// of one fp32 scale per row, so that a producer can quantise the tile it holds -- the attention kernel its 64 context columns of a head, the
+// SwiGLU epilogue its 64 gated columns -- without knowing the row's maximum over ALL columns, which took a separate pass over the row
+// (quant_rows_fp8_kernel: 7 % of the ViT-g forward).  v_mfma_scale_f32_32x32x64_f8f6f4 takes exactly that: a lane supplies the 32 bytes of
+// one block of its row and, in the scale operand, that block's byte (op_sel picks one of the four bytes of the VGPR).  W keeps its
+// per-output-feature fp32 scale (epilogue) and contributes the constant block scale 2^0.
+// Scale layout As [M][2][K / 64] (row pitch K / 32 bytes): the bytes of a (row, 32-byte half h of the K-tile) for FOUR consecutive K-tiles are
+// one aligned dword, so the eight waves bring the scales of a group of four K-tiles with ONE 4-byte-per-lane LDS-DMA each (256 rows x 2
+// halves x 4 B = 2 KiB, double-buffered behind the ring) -- no register load competes with the ring's vmcnt.  K % 256 == 0.
+// Which bytes a lane's scale covers was MEASURED (tools/mx_probe.py: one element doubled, one block switched on): the instruction's K block b is
+// the FIRST 16 bytes (b = 0) or the LAST 16 bytes (b = 1) of every lane's 32, from both lane halves, and its scale is read from lanes 32b ..
+// 32b + 31.  So lane half g takes the 16-byte chunks g and g + 2 of a row's 64-byte K-tile (not 2g and 2g + 1 as the unscaled kernel, where
+// any byte order both operands share is a dot product): chunks 0, 1 -- the row's first 32 elements -- are then the instruction's block 0.
+// vmcnt per wave and K-tile: 3 ring pieces, plus the scale piece of the NEXT group issued in the first iteration of a group; at the top of
+// iteration kt everything issued in iteration kt - 1 may still fly: 3, or 4 when kt - 1 opened a group that has a successor.
+#define F8_SC_BYTES 2048
+__global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsigned char* __restrict__ A, int lda,
+                                                                    const unsigned char* __restrict__ W, int ldw,
+                                                                    int M, int N, int K, GemmEpi e, int GM) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_m = (M + F8M - 1) / F8M, tiles_n = (N + F8N - 1) / F8N;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  {
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = bid - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
+  const int m0 = tm * F8M, n0 = tn * F8N;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const unsigned char* gA0; const unsigned char* gA1; const unsigned char* gW0; const unsigned char* gS;
+  {
+    auto src = [&](const unsigned char* base, int ld, int r0, int piece, int lim) {
+      const int rl = piece * 16 + (lane >> 2);
+      int r = r0 + rl; r = r < lim ? r : lim - 1;
+      return base + (size_t)r * ld + swz64(rl, lane & 3) * 16;
+    };
+    gA0 = src(A, lda, m0, wid * 2, M); gA1 = src(A, lda, m0, wid * 2 + 1, M);
+    gW0 = src(W, ldw, n0, wid, N);
+    // scale piece of this wave: LDS dword index wid * 64 + lane = tile row * 2 + half
+    const int sidx = wid * 64 + lane;
+    int r = m0 + (sidx >> 1); r = r < M ? r : M - 1;
+    gS = e.a_bs + (size_t)r * (K >> 5) + (size_t)(sidx & 1) * (K >> 6);
+  }
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  char* const sc_base = smem + F8_SLOTS * F8_STAGE;                   // two 2-KiB scale buffers behind the ring
+#define STAGE8M(slot_, k0)                                                                                 \
+  {                                                                                                        \
+    char* sA_ = smem + (slot_) * F8_STAGE + wu * 2048;                                                     \
+    char* sW_ = smem + (slot_) * F8_STAGE + F8M * F8K + wu * 1024;                                         \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (k0)), (lptr_t)(sA_), 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (k0)), (lptr_t)(sA_ + 1024), 16, 0, 0);                \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sW_), 16, 0, 0);                       \
+  }
+#define STAGE8S(g_) __builtin_amdgcn_global_load_lds((gptr_t)(gS + 4 * (g_)), (lptr_t)(sc_base + ((g_) & 1) * F8_SC_BYTES + wu * 256), 4, 0, 0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = K / F8K, ng = nk >> 2;
+  const int lr = lane & 31, lh = lane >> 5;
+  STAGE8S(0)
+  STAGE8M(0, 0)
+  STAGE8M(1, F8K)                      // nk >= 4
+  int offA[2], offW[2], offS[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 64 + i * 32 + lr;
+    offA[i] = row * 64 + swz64(row, lh) * 16;
+    offS[i] = (row * 2 + lh) * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offW[j] = F8M * F8K + row * 64 + swz64(row, lh) * 16; }
+  int slot = 0;
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  int sca[2] = {0, 0};
+  for (int kt = 0; kt < nk; ++kt) {
+    const int u = kt & 3, g = kt >> 2;                 // wave-uniform
+    const bool has_next = g + 1 < ng;
+    if (kt + 1 < nk) {
+      if (u == 1 && has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (u == 0 && has_next) STAGE8S(g + 1)
+    if (kt + 2 < nk) {
+      const int ns = slot >= 1 ? slot - 1 : 2;
+      STAGE8M(ns, (kt + 2) * F8K)
+    }
+    const char* st = smem + slot * F8_STAGE;
+    if (u == 0) {       // this group's scale dwords (read as ushort pairs: an int-typed read "may alias" the pending LDS-DMA writes)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) sca[i] = __builtin_bit_cast(int, *reinterpret_cast<const us2*>(sc_base + (g & 1) * F8_SC_BYTES + offS[i]));
+    }
+    i32x8 af[2], wf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const i32x4 lo = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + offA[i]));
+      const i32x4 hi = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ 32)));
+      af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const i32x4 lo = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + offW[j]));
+      const i32x4 hi = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ 32)));
+      wf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int sb = (int)((unsigned)sca[i] >> (8 * u));      // this K-tile's byte into byte 0 (op_sel 0)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)   // W: constant block scale 2^0 (byte 127)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 127, 0, sb);
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+#undef STAGE8M
+#undef STAGE8S
+  constexpr int PITCH = F8N * 4 + 16;
+  const ColParams cp = load_col_params<F8N>(e, n0, N, tid);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      stage_acc(smem, PITCH, wm * 32 + lr, wn * 64 + j * 32, acc[pass][j], lh);
+    __syncthreads();
+    drain_tile<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
+                              [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+  }
+}
+
+static constexpr int LDS8MX = F8_SLOTS * F8_STAGE + 2 * F8_SC_BYTES;
 static constexpr int LDS8 = (128 * (F8N * 4 + 16)) > F8_SLOTS * F8_STAGE ? (128 * (F8N * 4 + 16)) : F8_SLOTS * F8_STAGE;
 
 int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int ldw, int M, int N, int K,
@@ -142,7 +293,17 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
-  if (!e.a_scale || !e.w_scale) return 2;
+  if (!e.w_scale || (!e.a_scale && !e.a_bs)) return 2;
+  if (e.a_bs) {          // block-scaled activations
+    if (K % 256 != 0) return 2;
+    static bool attr_mx = false;
+    if (!attr_mx) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8MX); attr_mx = true; }
+    static const char* gmx = getenv("DINODET_GEMM_GM");
+    const int gm = gmx ? atoi(gmx) : (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2));
+    const int tiles = ((M + F8M - 1) / F8M) * ((N + F8N - 1) / F8N);
+    hipLaunchKernelGGL(gemm_fp8mx_256x128_kernel, dim3(tiles), dim3(512), LDS8MX, s, A, lda, W, ldw, M, N, K, e, gm);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+  }
   {
     // the 256x256 ping-pong kernel (gemm_pp.hip) where the K loop is long enough to pay for its one-workgroup-per-CU prologue /
     // epilogue; measured (tools/bench_fp8.py, DINODET_FP8_TILE = p / o forces either kernel): ViT-g, 32 x 518^2: QKV (K 1536) 449 vs
@@ -197,6 +358,45 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
     const float4 v = ld4(c);
     *reinterpret_cast<unsigned*>(q + (size_t)row * ldq + c) = pack4_fp8(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
   }
+}
+
+// Block-scaled quantisation of whole rows (dod_common.h "MX"): one wave per row, a block of 32 elements = 8 lanes x 4.  The forward's
+// producers (attention epilogue, SwiGLU epilogue) quantise their own tiles with the same two helpers; this kernel is the operator-level
+// form (tests, tools) and the fallback where a producer cannot (cols % 32 == 0).
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void quant_mx_fp8_kernel(const void* __restrict__ xin, int ld, int rows, int cols,
+                                                           unsigned char* __restrict__ q, int ldq, unsigned char* __restrict__ bs) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  for (int c0 = 0; c0 < cols; c0 += 256) {
+    const int c = c0 + lane * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols) {
+      if (IN_BF16) {
+        const uint2 u = *reinterpret_cast<const uint2*>((const bf16_t*)xin + (size_t)row * ld + c);
+        v = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+      } else v = *reinterpret_cast<const float4*>((const float*)xin + (size_t)row * ld + c);
+    }
+    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const unsigned eb = mx_ebyte(amax);
+    const float inv = mx_inv_scale(eb);
+    if (c < cols) {
+      *reinterpret_cast<unsigned*>(q + (size_t)row * ldq + c) = pack4_fp8(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+      if ((lane & 7) == 0) bs[(size_t)row * (cols >> 5) + mx_scale_off(cols, c >> 5)] = (unsigned char)eb;
+    }
+  }
+}
+int launch_quant_mx_fp8(const void* x, int in_bf16, int ld, int rows, int cols, unsigned char* q, int ldq, unsigned char* bs, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 1;
+  if (cols % 64 != 0 || ld % 4 != 0 || ldq % 4 != 0) return 2;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (in_bf16) hipLaunchKernelGGL(quant_mx_fp8_kernel<true>, grid, block, 0, s, x, ld, rows, cols, q, ldq, bs);
+  else hipLaunchKernelGGL(quant_mx_fp8_kernel<false>, grid, block, 0, s, x, ld, rows, cols, q, ldq, bs);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
 int launch_quant_rows_fp8(const void* x, int in_bf16, int ld, int rows, int cols, unsigned char* q, int ldq, float* scale,

@@ -176,6 +176,13 @@ int dod_op_linear_fp8(const void* A, int lda, const float* a_scale, const void* 
  * row); q = round-to-nearest-even e4m3 of x / scale */
 int dod_op_quant_rows_fp8(const void* x, int in_dtype, int ld, int rows, int cols, void* q, int ldq, float* scale,
                           void* stream);
+/* Block-scaled ("MX") activations of the fp8 GEMM: x [rows, cols] (cols % 64 == 0) -> q e4m3 [rows, ldq] and one e8m0 byte per 32 elements
+ * (value 2^(byte - 127): the smallest power of two >= amax_block / 448), laid out [rows][2][cols / 64]: block b of a row at byte
+ * (b & 1) * (cols / 64) + (b >> 1).  dod_op_linear_fp8_mx: the linear on such an A (K % 256 == 0), W as in dod_op_linear_fp8. */
+int dod_op_quant_mx_fp8(const void* x, int in_dtype, int ld, int rows, int cols, void* q, int ldq, void* block_scales, void* stream);
+int dod_op_linear_fp8_mx(const void* A, int lda, const void* a_block_scales, const void* W, int ldw, const float* w_scale,
+                         int M, int N, int K, const float* bias, const float* scale, const float* resid, int ldr,
+                         void* out, int out_dtype, int ldc, int act, void* stream);
 /* bf16x3 (parity-gated mode) operators.  Pair layout: [rows, 2*cols] bf16 = [hi | lo], hi = bf16(x), lo = bf16(x - hi).
  * dod_op_split_pair: fp32 x [rows, cols] (ld) -> pair layout.
  * dod_op_linear_x3: A2 [M, 2K], W2 [N, 2K] pair layouts -> act(A W^T + bias) * scale + resid as the split product

@@ -74,6 +74,28 @@ def _q8(t):
     return (t * (1.0 / sc)).to(torch.float8_e4m3fn).to(t.dtype) * sc
 
 
+def _mx_scales(t):
+    """e8m0 block scales of the fp8 path's block-scaled activations (dinov2_od_amd/csrc/dod_common.h mx_ebyte): one byte per 32 elements of
+    the last dimension, 2^(byte - 127) = the smallest power of two >= amax_block / 448 (fp32 arithmetic: amax * fp32(1 / 448)); a zero
+    block gets byte 1.  Returns the biased bytes, shape [..., K / 32] (int64)."""
+    K = t.shape[-1]
+    amax = t.float().reshape(*t.shape[:-1], K // 32, 32).abs().amax(-1)
+    tt = amax * (torch.tensor(1.0, dtype=torch.float32) / 448.0)
+    m, ex = torch.frexp(tt)                       # tt = m * 2^ex, m in [0.5, 1)
+    e = torch.where(m > 0.5, ex, ex - 1)          # ceil(log2(tt))
+    return torch.where(amax > 0, (e.long() + 127).clamp(1, 253), torch.ones_like(e, dtype=torch.long))
+
+
+def _q8_mx(t):
+    """block-scaled e4m3 fake quantisation of the last dimension (K % 32 == 0); returns the dequantised values q * 2^e (exact)"""
+    K = t.shape[-1]
+    eb = _mx_scales(t)
+    sc = torch.pow(torch.tensor(2.0, dtype=torch.float64), (eb - 127).double()).to(t.dtype)
+    x = t.reshape(*t.shape[:-1], K // 32, 32)
+    q = (x * (1.0 / sc)[..., None]).to(torch.float8_e4m3fn).to(t.dtype) * sc[..., None]
+    return q.reshape(t.shape)
+
+
 def _e4m3(t):
     return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(t.dtype)
 

@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from dinov2_od_amd import _native as nat, synth
-from tests.cases import rel_err
+from tests.cases import rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 ACC_TOL = 1e-4
@@ -75,6 +75,81 @@ def test_linear_fp8_all_epilogues(M, N, K):
     assert rel_err(run(bias.cuda(), act="gelu", out_dtype=torch.bfloat16).float().cpu().numpy(), want.numpy()) < 2 ** -7
     want = (ref + bias.double()) * scale.double() + resid.double()
     assert rel_err(run(bias.cuda(), scale.cuda(), resid.cuda()).cpu().numpy(), want.numpy()) < ACC_TOL
+
+
+def mx_ref(x):
+    """block-scaled quantisation as the oracle defines it: e4m3 values [rows, K] and the e8m0 bytes in the kernel's [rows][2][K / 64] layout"""
+    from oracle import dinodet_oracle as orc
+    x = x.float()
+    rows, K = x.shape
+    eb = orc._mx_scales(x)                                            # [rows, K / 32], block order
+    sc = torch.pow(torch.tensor(2.0, dtype=torch.float64), (eb - 127).double()).float()
+    q = (x.reshape(rows, K // 32, 32) * (1.0 / sc)[..., None]).to(torch.float8_e4m3fn).reshape(rows, K)
+    lay = eb.reshape(rows, K // 64, 2).permute(0, 2, 1).reshape(rows, K // 32).to(torch.uint8)       # block b -> (b & 1) * K / 64 + (b >> 1)
+    return q, lay, sc
+
+
+def mx_gpu(x):
+    L = nat.lib()
+    rows, cols = x.shape
+    q = torch.empty(rows, cols, dtype=torch.uint8, device=x.device)
+    bs = torch.empty(rows, cols // 32, dtype=torch.uint8, device=x.device)
+    nat.check(L.dod_op_quant_mx_fp8(nat.ptr(x), nat.DOD_BF16 if x.dtype == torch.bfloat16 else nat.DOD_F32, x.stride(0), rows, cols,
+                                    nat.ptr(q), cols, nat.ptr(bs), nat.stream_ptr()))
+    return q, bs
+
+
+@pytest.mark.parametrize("rows,cols,dt", [(5, 64, torch.float32), (1000, 1536, torch.float32), (333, 4096, torch.bfloat16)])
+def test_quant_mx_is_bit_exact(rows, cols, dt):
+    """block-scaled ("MX") activations: bytes and e8m0 block scales against the oracle's definition (torch float8_e4m3fn), blocks of very
+    different magnitude, an all-zero block, and exact powers of two at the block maximum (the ceil of the scale rule)"""
+    x = torch.from_numpy(_n(f"mx.{rows}.{cols}", (rows, cols), 2.0))
+    x[0, :32] *= 1e-4
+    x[1, 32:64] = 0
+    x[2, :32] = 0.25; x[2, 5] = 448.0 * 4          # amax / 448 exactly a power of two
+    x[3, :32] *= 300.0
+    x = x.to(dt)
+    qr, lay, _ = mx_ref(x)
+    qg, bg = mx_gpu(x.cuda())
+    assert torch.equal(bg.cpu(), lay)
+    assert torch.equal(qg.cpu(), qr.view(torch.uint8))
+
+
+@pytest.mark.parametrize("M,N,K", [(515, 384, 1536), (4110 + 7, 1536, 4096), (300, 128, 256)])
+def test_linear_fp8_mx_block_scaled_activations(M, N, K):
+    """the fp8 GEMM with block-scaled A (one e8m0 byte per 32 k, applied by v_mfma_scale_f32_32x32x64_f8f6f4) and per-output-feature W
+    scales: against the exact products of the same operands; rows of very different block magnitudes"""
+    L = nat.lib()
+    A = torch.from_numpy(_n(f"mx.A.{M}.{K}", (M, K)))
+    A[:, : K // 2] *= 40.0                        # blocks of very different magnitude inside every row
+    A[1::3] *= 1e-2
+    W = torch.from_numpy(_n(f"mx.W.{N}.{K}", (N, K), 0.05))
+    qa, lay, sc = mx_ref(A)
+    qw, sw = quant_ref(W)
+    a_deq = (qa.float().reshape(M, K // 32, 32) * sc[..., None]).reshape(M, K).double()
+    ref = (a_deq @ qw.double().t()) * sw.double()[None, :]
+    bias, scale, resid = torch.from_numpy(_n("mx.b", (N,))), 1 + torch.from_numpy(_n("mx.s", (N,), 0.1)), torch.from_numpy(_n("mx.r", (M, N)))
+    qa_d, bs_d, qw_d, sw_d = qa.view(torch.uint8).cuda(), lay.cuda(), qw.view(torch.uint8).cuda(), sw.cuda()
+
+    def run(bias=None, scale=None, resid=None, act="none", out_dtype=torch.float32):
+        out = torch.empty(M, N, dtype=out_dtype, device="cuda")
+        nat.check(L.dod_op_linear_fp8_mx(nat.ptr(qa_d), K, nat.ptr(bs_d), nat.ptr(qw_d), K, nat.ptr(sw_d), M, N, K, nat.ptr(bias), nat.ptr(scale),
+                                         nat.ptr(resid), N if resid is not None else 0, nat.ptr(out),
+                                         nat.DOD_BF16 if out_dtype == torch.bfloat16 else nat.DOD_F32, N, nat.ACT[act], nat.stream_ptr()))
+        return out
+
+    err = rel_err(run().cpu().numpy(), ref.numpy())
+    print(f"fp8 mx gemm M={M} N={N} K={K}: rel err vs exact products {err:.2e}")
+    assert err < ACC_TOL
+    want = (ref + bias.double()) * scale.double() + resid.double()
+    assert rel_err(run(bias.cuda(), scale.cuda(), resid.cuda()).cpu().numpy(), want.numpy()) < ACC_TOL
+    # block scales are as accurate as one exact scale per row (e4m3 keeps 3 mantissa bits at any scale; a power of two costs range, not bits)
+    qa_r, sa_r = quant_ref(A)
+    per_row = (qa_r.double() * sa_r.double()[:, None]) @ qw.double().t() * sw.double()[None, :]
+    exact = A.double() @ (qw.double() * sw.double()[:, None]).t()
+    e_mx, e_row = rel_l2(ref.numpy(), exact.numpy()), rel_l2(per_row.numpy(), exact.numpy())
+    print(f"  distance to the unquantised-A product: block-scaled {e_mx:.2e}, per-row {e_row:.2e}")
+    assert e_mx < 1.1 * e_row
 
 
 def test_linear_fp8_rejects_bad_shapes():
