@@ -37,7 +37,9 @@ def quant_gpu(x):
     return q, sc
 
 
-@pytest.mark.parametrize("rows,cols,dt", [(5, 64, torch.float32), (1000, 1536, torch.float32), (333, 4096, torch.bfloat16), (2, 8, torch.float32)])
+@pytest.mark.parametrize("rows,cols,dt", [(5, 64, torch.float32), (1000, 1536, torch.float32), (333, 4096, torch.bfloat16), (2, 8, torch.float32),
+                                          (101, 1536, torch.bfloat16), (7, 64, torch.bfloat16), (50, 2048, torch.bfloat16), (9, 520, torch.bfloat16),
+                                          (3, 4100, torch.bfloat16)])       # bf16 rows up to 4096 wide: the register-resident kernel; beyond: the two-pass one
 def test_quant_rows_is_bit_exact(rows, cols, dt):
     x = torch.from_numpy(_n(f"q.{rows}.{cols}", (rows, cols), 2.0)).to(dt)
     x[0, :] *= 1e-3          # a small-magnitude row
