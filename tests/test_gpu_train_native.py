@@ -96,8 +96,8 @@ def test_native_decoder_backward_matches_composite_autograd(case):
         finally:
             os.environ.pop("DINODET_MHA_CHUNK_IMAGES", None)
         assert torch.equal(l2, l1) and torch.equal(b2, b1)
-        for k in g1:        # weight gradients accumulate atomically: equal up to the order of fp32 additions
-            assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 2e-6, k
+        for k in g1:        # weight gradients accumulate atomically: equal up to the order of fp32 additions (a bias gradient is a sum of
+            assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-5, k     # B*Q terms of both signs: 2.4e-6 seen on one box, 1e-6 typical)
 
 
 def test_native_decoder_dropout_masks_are_consistent_and_seeded():
