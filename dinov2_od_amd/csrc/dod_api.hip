@@ -447,7 +447,7 @@ extern "C" void dod_debug_set_dec_fused_split(int mode) { g_dec_fused_split.stor
   if ((size_t)((c).base - (char*)(workspace)) + (c).off > (wsb))                                                              \
     return fail(h, DOD_ERR_STATE, "internal: workspace carve %zu exceeds the %zu bytes provided", (size_t)((c).base - (char*)(workspace)) + (c).off, (size_t)(wsb));
 struct DecWS { float *tgt, *t2, *att, *samp, *qkv, *proj, *ffn, *hb, *qd; void* mem_op; float* values; float* kv; bf16_t* a3; bf16_t* a3b; bf16_t* mem2; };   // mem2: bf16x3 mode, memory in the pair layout [M, 2*Dd]
-struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; float* rs; };   // rs: fp8 mode, per-row activation scales [M]
+struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; float* rs; unsigned char* bs; };   // rs: fp8 mode, per-row activation scales [M]
 
 size_t carve_decoder(const dod_handle* h, Carver& c, int B, int N, DecWS* w, bool need_mem_op) {
   const dod_config& g = h->cfg;
@@ -486,6 +486,7 @@ size_t carve_backbone(const dod_handle* h, Carver& c, int B, int N, BbWS* w) {
   t.hbuf = c.take(hb * es); t.gated = g.swiglu ? c.take(M * (size_t)g.ffn_hidden * es) : nullptr;
   t.mem = c.take(M * (size_t)(g.target_dim ? g.target_dim : g.hidden) * es);
   t.rs = is_fp8(h) ? (float*)c.take(M * 4) : nullptr;
+  t.bs = (is_fp8(h) && g.swiglu && g.ffn_hidden % 256 == 0) ? (unsigned char*)c.take(M * (size_t)(g.ffn_hidden / 32)) : nullptr;     // e8m0 block scales of the gated rows
   if (w) *w = t;
   return c.off;
 }
@@ -545,7 +546,7 @@ int linear_h2(dod_handle* h, const void* A, const void* W, const unsigned char* 
 // fp8 linear: A_q [M,K] e4m3 with per-row scales, W_q [N,K] e4m3 with per-row (output feature) scales
 int linear8(dod_handle* h, const void* A, const float* a_scale, const void* W, const float* w_scale, int M, int N, int K, GemmEpi e, hipStream_t s) {
   ProfScope ps(h, s, PC_GEMM_FP8, 2.0 * M * N * (double)K);
-  e.a_scale = a_scale; e.w_scale = w_scale;
+  e.a_scale = a_scale; e.w_scale = w_scale;      // (a_scale null with e.a_bs set: block-scaled activations)
   int r = launch_gemm_fp8((const unsigned char*)A, K, (const unsigned char*)W, K, M, N, K, e, s);
   if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "fp8 linear launch rejected (M=%d N=%d K=%d rc=%d)", M, N, K, r);
   return 0;
@@ -594,6 +595,9 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   const float scale = 1.0f / std::sqrt((float)(D / g.heads));
   float* yf = bf ? nullptr : (float*)ws.y; bf16_t* yb = bf ? (bf16_t*)ws.y : nullptr;
   const bool f8 = is_fp8(h);   // LayerNorm / SwiGLU emit e4m3 rows + per-row scales (ws.rs) for the QKV / MLP linears
+  // fp8 SwiGLU: block-scaled gated rows written by the weights_in epilogue (F % 256 == 0; DINODET_FP8_MX_GATE=0: bf16 rows + a quantisation pass)
+  static const bool mx_gate_env = [] { const char* v = getenv("DINODET_FP8_MX_GATE"); return !(v && v[0] == '0'); }();
+  const bool mx_gate = mx_gate_env && g.ffn_hidden % 256 == 0;
   const bool x3 = is_x3(h);
   const int nblocks = stop_blocks >= 0 ? (stop_blocks < g.layers ? stop_blocks : g.layers) : g.layers;
   for (int i = 0; i < nblocks; ++i) {
@@ -669,7 +673,14 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
     }
     if (f8) {
       { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, (unsigned char*)ws.y, ws.rs)); }
-      if (g.swiglu && L.glu) {     // gate fused into the GEMM epilogue: [M, F] bf16, then the row quantisation of the MLP-out operand
+      if (g.swiglu && L.glu && ws.bs && mx_gate) {
+        // gate AND quantisation in the weights_in epilogue: e4m3 gated rows with one e8m0 scale per 32 columns (no bf16 hidden rows, no
+        // row-quantisation pass over them); weights_out takes the block scales in its MFMAs (gemm_fp8.hip)
+        GemmEpi eg = epi(L.b1, nullptr, ws.gated, F); eg.glu = 1; eg.out_bs = ws.bs;
+        rc = linear8(h, ws.y, ws.rs, L.W1, L.s1, M, 2 * F, D, eg, s); if (rc) return rc;
+        GemmEpi e2 = epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D); e2.a_bs = ws.bs;
+        rc = linear8(h, ws.gated, nullptr, L.W2, L.s2, M, D, F, e2, s); if (rc) return rc;
+      } else if (g.swiglu && L.glu) {     // gate fused into the GEMM epilogue: [M, F] bf16, then the row quantisation of the MLP-out operand
         GemmEpi eg = epi(L.b1, nullptr, ws.hbuf, F); eg.glu = 1;
         rc = linear8(h, ws.y, ws.rs, L.W1, L.s1, M, 2 * F, D, eg, s); if (rc) return rc;
         KCHK(h, launch_quant_rows_fp8(ws.hbuf, 1, F, M, F, (unsigned char*)ws.gated, F, ws.rs, s));
@@ -1172,6 +1183,15 @@ int dod_op_linear_fp8_mx(const void* A, int lda, const void* a_block_scales, con
   e.a_bs = (const unsigned char*)a_block_scales; e.w_scale = w_scale;
   int r = launch_gemm_fp8((const unsigned char*)A, lda, (const unsigned char*)W, ldw, M, N, K, e, (hipStream_t)stream);
   if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear_fp8_mx rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
+  return DOD_OK;
+}
+int dod_op_linear_fp8_glu_mx(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, int M, int N, int K,
+                             const float* bias, void* out_q, int ldq, void* out_block_scales, void* stream) {
+  if (!A || !W || !a_scale || !w_scale || !out_q || !out_block_scales) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  GemmEpi e = epi(bias, nullptr, out_q, ldq);
+  e.a_scale = a_scale; e.w_scale = w_scale; e.glu = 1; e.out_bs = (unsigned char*)out_block_scales;
+  int r = launch_gemm_fp8((const unsigned char*)A, lda, (const unsigned char*)W, ldw, M, N, K, e, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear_fp8_glu_mx rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
   return DOD_OK;
 }
 int dod_op_quant_mx_fp8(const void* x, int in_dtype, int ld, int rows, int cols, void* q, int ldq, void* block_scales, void* stream) {

@@ -133,6 +133,7 @@ struct GemmEpi {
                           // < 0 pair layout [hi | lo], each -out_split wide (ldc = -2*out_split)
   const float* a_scale;   // fp8 GEMM only: per-row (token) dequant scale of A, [M]; null otherwise
   const float* w_scale;   // fp8 GEMM only: per-output-feature dequant scale of W, [N]
+  unsigned char* out_bs;       // fp8 GEMM with glu only: the gated rows leave as e4m3 (out_bf16 = byte rows, pitch ldc bytes) with these e8m0 block scales [M][2][F / 64]
   const unsigned char* a_bs;   // fp8 GEMM only: e8m0 BLOCK scales of A (one byte per 32 elements along K, layout [M][2][K / 64]: gemm_fp8.hip) instead of a_scale
   int out_h2;             // with out_bf16: H2 activation rows (above) of N columns at row pitch ldc (2-byte units, >= 2N)
   const unsigned char* h2_wexp;   // H2 GEMM only: E8M0 byte (127 - e) of every weight row's e4m3 scale 2^e, [N]

@@ -24,6 +24,39 @@
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// SwiGLU epilogue of the weights_in GEMM that QUANTISES what it gates (GemmEpi::out_bs set): interleaved pair columns (x1, x2) -> gated value,
+// 64 gated columns per tile row = two blocks of 32 = 16 consecutive threads each; block maximum by four shuffles, e8m0 byte + e4m3 bytes
+// straight from the fp32 gate -- the bf16 hidden rows and the row-quantisation pass over them (97 us per ViT-g block) disappear; the next
+// GEMM (weights_out) takes the block scales in its MFMAs (gemm_fp8mx_256x128_kernel).  e.out_bf16 = e4m3 rows, pitch e.ldc BYTES (= N / 2).
+template <int ROWS, int COLS, int NT, class RowMap>
+__device__ __forceinline__ void drain_glu_mx(const char* sm, int pitch, const GemmEpi& e, const ColParams& cp, int M, int N, int n0, int tid,
+                                             RowMap rowmap) {
+  constexpr int C4 = COLS / 4;
+  const int c4 = tid % C4, n = n0 + 4 * c4, F = N >> 1;
+  unsigned char* q8 = reinterpret_cast<unsigned char*>(e.out_bf16);
+#pragma unroll
+  for (int row_l = tid / C4; row_l < ROWS; row_l += NT / C4) {
+    const int m = rowmap(row_l);
+    const bool ok = m < M && n < N;
+    float4 v = *reinterpret_cast<const float4*>(sm + row_l * pitch + c4 * 16);
+    const float sa = e.a_scale ? e.a_scale[m < M ? m : M - 1] : 1.0f;
+    v.x = v.x * (sa * cp.wscale.x) + cp.bias.x; v.y = v.y * (sa * cp.wscale.y) + cp.bias.y;
+    v.z = v.z * (sa * cp.wscale.z) + cp.bias.z; v.w = v.w * (sa * cp.wscale.w) + cp.bias.w;
+    const float g0 = ok ? silu_mul(v.x, v.y) : 0.f, g1 = ok ? silu_mul(v.z, v.w) : 0.f;
+    float amax = fmaxf(fabsf(g0), fabsf(g1));              // every lane takes part in the shuffles (rows past M contribute zeros)
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 8, 64));
+    if (!ok) continue;
+    const unsigned eb = mx_ebyte(amax);
+    const float inv = mx_inv_scale(eb);
+    const int gc = n >> 1;                                  // gated column
+    *reinterpret_cast<unsigned short*>(q8 + (size_t)m * e.ldc + gc) = (unsigned short)(pack4_fp8(g0 * inv, g1 * inv, 0.f, 0.f) & 0xffffu);
+    if ((c4 & 15) == 0) e.out_bs[(size_t)m * (F >> 5) + mx_scale_off(F, gc >> 5)] = (unsigned char)eb;
+  }
+}
+
 __global__ __launch_bounds__(512, 4) void gemm_fp8_256x128_kernel(const unsigned char* __restrict__ A, int lda,
                                                                   const unsigned char* __restrict__ W, int ldw,
                                                                   int M, int N, int K, GemmEpi e, int GM) {
@@ -129,8 +162,9 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8_256x128_kernel(const unsigned
     for (int j = 0; j < 2; ++j)
       stage_acc(smem, PITCH, wm * 32 + lr, wn * 64 + j * 32, acc[pass][j], lh);
     __syncthreads();
-    drain_tile<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                              [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+    if (e.out_bs) drain_glu_mx<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+    else drain_tile<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
+                                   [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
   }
 }
 
@@ -294,6 +328,7 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
   if (!e.w_scale || (!e.a_scale && !e.a_bs)) return 2;
+  if (e.out_bs && (!e.glu || !e.out_bf16 || N % 128 != 0 || e.scale || e.resid || e.act != ACT_NONE)) return 2;
   if (e.a_bs) {          // block-scaled activations
     if (K % 256 != 0) return 2;
     static bool attr_mx = false;
@@ -313,7 +348,7 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
     // the QKV / MLP-in linears it still loses (68.8 vs 63.5 ms: in the forward their operands arrive from the producing kernels, not
     // from a warm cache).  Kept as an opt-in (DINODET_FP8_TILE=p); the two-workgroups-per-CU kernel below stays the default
     static const char* v = getenv("DINODET_FP8_TILE");
-    const bool pp = v && v[0] == 'p';      // opt-in only: see above
+    const bool pp = v && v[0] == 'p' && !e.out_bs;      // opt-in only: see above
     if (pp && K % 128 == 0) return launch_gemm_fp8_pp(A, lda, W, ldw, M, N, K, e, s);
   }
   static bool attr_set = false;

@@ -183,6 +183,11 @@ int dod_op_quant_mx_fp8(const void* x, int in_dtype, int ld, int rows, int cols,
 int dod_op_linear_fp8_mx(const void* A, int lda, const void* a_block_scales, const void* W, int ldw, const float* w_scale,
                          int M, int N, int K, const float* bias, const float* scale, const float* resid, int ldr,
                          void* out, int out_dtype, int ldc, int act, void* stream);
+/* The ViT-g fp8 MLP-in linear with the SwiGLU gate AND the block-scaled quantisation of the gated row in its epilogue: W [N, K] holds the
+ * (x1_i, x2_i) rows interleaved (N = 2F, N % 128 == 0); out_q [M, F] e4m3 (pitch ldq bytes) = silu(x1) * x2 / 2^e per 32 columns, the
+ * e8m0 bytes in out_block_scales in the dod_op_quant_mx_fp8 layout -- the A operand of dod_op_linear_fp8_mx. */
+int dod_op_linear_fp8_glu_mx(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale,
+                             int M, int N, int K, const float* bias, void* out_q, int ldq, void* out_block_scales, void* stream);
 /* bf16x3 (parity-gated mode) operators.  Pair layout: [rows, 2*cols] bf16 = [hi | lo], hi = bf16(x), lo = bf16(x - hi).
  * dod_op_split_pair: fp32 x [rows, cols] (ld) -> pair layout.
  * dod_op_linear_x3: A2 [M, 2K], W2 [N, 2K] pair layouts -> act(A W^T + bias) * scale + resid as the split product

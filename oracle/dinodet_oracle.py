@@ -119,7 +119,8 @@ def _linear(x, w, b, emu, fp8=False):
         y = _h2_product(x, w)
         return y if b is None else y + b
     if emu and fp8:
-        x, w = _q8(x), _q8(w)          # per-token activation scales, per-output-feature weight scales
+        # per-token activation scales, per-output-feature weight scales; fp8 == "w": the activation arrives already quantised (block-scaled)
+        x, w = (x if fp8 == "w" else _q8(x)), _q8(w)
     elif emu:
         x, w = _bf(x), _bf(w)
     y = x @ w.t()
@@ -263,9 +264,13 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
             z = _maybe_lora_linear(sd, lp + "mlp.weights_in", y, a, emu_lin, f8)
             x1, x2 = z.chunk(2, dim=-1)
             z = F.silu(x1) * x2
-            if f8:
-                z = _bf(z)              # the fp8 path gates in the MLP-in GEMM's epilogue (fp32), stores the hidden rows in bf16, then quantises them
-            z = _maybe_lora_linear(sd, lp + "mlp.weights_out", z, a, emu_lin, f8)
+            if f8 and z.shape[-1] % 256 == 0:
+                # the fp8 path gates in the MLP-in GEMM's epilogue (fp32) and quantises there: e4m3 with one power-of-two scale per 32 columns
+                z = _maybe_lora_linear(sd, lp + "mlp.weights_out", _q8_mx(z), a, emu_lin, "w")
+            else:
+                if f8:
+                    z = _bf(z)          # other widths: bf16 hidden rows, then one scale per row
+                z = _maybe_lora_linear(sd, lp + "mlp.weights_out", z, a, emu_lin, f8)
         else:
             z = _maybe_lora_linear(sd, lp + "mlp.fc1", y, a, emu_lin, f8)
             z = 0.5 * z * (1.0 + torch.erf(z / math.sqrt(2.0)))   # exact-erf GELU

@@ -154,6 +154,51 @@ def test_linear_fp8_mx_block_scaled_activations(M, N, K):
     assert e_mx < 1.1 * e_row
 
 
+@pytest.mark.parametrize("M,F,K", [(515, 256, 256), (1000 + 3, 4096, 1536)])
+def test_linear_fp8_glu_epilogue_quantises_block_scaled(M, F, K):
+    """weights_in of the fp8 SwiGLU MLP: gate and block-scaled quantisation in the GEMM epilogue.  The dequantised output against
+    silu(x1) * x2 of the exact products of the same fp8 operands (e4m3 noise: 2^-4 per element), and against the oracle's own block-scaled
+    quantisation of that reference (the two differ only where an fp32-accumulation difference crosses a rounding boundary); then the
+    whole MLP tail: the epilogue's bytes and scales fed to the block-scaled GEMM."""
+    from oracle import dinodet_oracle as orc
+    L = nat.lib()
+    A = torch.from_numpy(_n(f"glu.A.{M}.{K}", (M, K)))
+    W1 = torch.from_numpy(_n(f"glu.W.{F}.{K}", (2 * F, K), 0.03))          # rows 0..F-1: x1, F..2F-1: x2 (modeling_dinov2.py:310-314)
+    b1 = torch.from_numpy(_n(f"glu.b.{F}", (2 * F,), 0.1))
+    Wi = torch.stack([W1[:F], W1[F:]], 1).reshape(2 * F, K)                 # the interleaved (x1_i, x2_i) row order the epilogue gates
+    bi = torch.stack([b1[:F], b1[F:]], 1).reshape(2 * F)
+    qa, sa = quant_ref(A)
+    qw, sw = quant_ref(Wi)
+    z = (qa.double() @ qw.double().t()) * sa.double()[:, None] * sw.double()[None, :] + bi.double()
+    ref = (F_silu(z[:, 0::2]) * z[:, 1::2]).float()
+    out_q = torch.empty(M, F, dtype=torch.uint8, device="cuda")
+    out_bs = torch.empty(M, F // 32, dtype=torch.uint8, device="cuda")
+    qa_d, sa_d, qw_d, sw_d, bi_d = qa.view(torch.uint8).cuda(), sa.cuda(), qw.view(torch.uint8).cuda(), sw.cuda(), bi.cuda()   # device copies that outlive the launch
+    nat.check(L.dod_op_linear_fp8_glu_mx(nat.ptr(qa_d), K, nat.ptr(sa_d), nat.ptr(qw_d), K, nat.ptr(sw_d),
+                                         M, 2 * F, K, nat.ptr(bi_d), nat.ptr(out_q), F, nat.ptr(out_bs), nat.stream_ptr()))
+    torch.cuda.synchronize()
+    eb = out_bs.cpu().reshape(M, 2, F // 64).permute(0, 2, 1).reshape(M, F // 32).long()        # back to block order
+    deq = (out_q.cpu().view(torch.float8_e4m3fn).float().reshape(M, F // 32, 32) * torch.pow(torch.tensor(2.0), (eb - 127).float())[..., None]).reshape(M, F)
+    e_ref, e_orc = rel_l2(deq.numpy(), ref.numpy()), rel_l2(deq.numpy(), orc._q8_mx(ref).numpy())
+    same_scales = float((eb == orc._mx_scales(ref)).float().mean())
+    print(f"glu + mx epilogue M={M} F={F}: vs exact gate {e_ref:.2e}, vs the oracle's quantisation of it {e_orc:.2e}, equal scale bytes {same_scales:.4f}")
+    assert e_ref < 4e-2 and e_orc < 1e-2 and same_scales > 0.995
+    if F % 256 == 0:      # ... and into weights_out on the block-scaled GEMM
+        D = 384
+        W2 = torch.from_numpy(_n(f"glu.W2.{F}", (D, F), 0.03))
+        qw2, sw2 = quant_ref(W2)
+        out = torch.empty(M, D, device="cuda")
+        qw2_d, sw2_d = qw2.view(torch.uint8).cuda(), sw2.cuda()
+        nat.check(L.dod_op_linear_fp8_mx(nat.ptr(out_q), F, nat.ptr(out_bs), nat.ptr(qw2_d), F, nat.ptr(sw2_d), M, D, F,
+                                         None, None, None, 0, nat.ptr(out), nat.DOD_F32, D, 0, nat.stream_ptr()))
+        want = deq.double() @ (qw2.double() * sw2.double()[:, None]).t()
+        assert rel_err(out.cpu().numpy(), want.numpy()) < ACC_TOL
+
+
+def F_silu(t):
+    return t / (1.0 + torch.exp(-t))
+
+
 def test_linear_fp8_rejects_bad_shapes():
     L = nat.lib()
     z = torch.zeros(64, 96, dtype=torch.uint8, device="cuda")
