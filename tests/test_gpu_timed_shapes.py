@@ -133,6 +133,54 @@ def test_timed_vitl_vitg_configurations_vs_reference(G, variant, B, precision):
     torch.cuda.empty_cache()
 
 
+# ------------------------------------------------------------------------------------------------ BASELINE configs[1]: ViT-B/14 224x224 x 32
+def _oracle_vitb224():
+    if "f32_224" not in _ORC:
+        bb, dc = cases.vitb(100, True)
+        sd = synth.detector_state_dict(bb, dc, seed=1)
+        x = synth.make_pixels(2, 224, 224, seed=0)
+        _ORC["f32_224"] = orc.detector_forward(sd, bb, dc, x)
+        _ORC["bf16_224"] = orc.detector_forward(sd, bb, dc, x, emulate_bf16=True)
+    return _ORC
+
+
+@pytest.mark.parametrize("precision", GATED + ["bf16"])
+def test_timed_vitb224_configuration_vs_reference_and_oracle(G, precision):
+    """BASELINE configs[1] as bench.py's `also.vitb224_*` legs run it (the resolution of the reference's own transform,
+    train.py:584-587): ViT-B/14 224x224, Q = 100, B = 32 -- 8 224 token rows (the 256x128_m16 kernel on 198 tiles, the K-split of the
+    underfilled N = 768 rounds in the compensated modes, bicubic position table) and 3 200 query rows (the 128x128 small-grid rule),
+    one stream, engine hipGraph on.  Image 0 against the reference's golden G3 (detector.py:58-69), images 0-1 against the CPU oracle;
+    fp32 additionally bit-equal to single-image launches."""
+    B = 32
+    bb, dc = cases.vitb(100, True)
+    m = G.make_detector(bb, dc, precision, "facebook/dinov2-base")
+    x = _bench_images(B, 224, G)
+    m.enable_hipgraph()
+    m.forward_packed(x)                                   # capture
+    det = m.forward_packed(x).clone()                     # replay
+    G.sync()
+    C = dc.num_classes
+    got_l, got_b = det[:2, :, :C].cpu().numpy(), det[:2, :, C:].cpu().numpy()
+    g = cases.golden("g3_vitb_224")
+    o = _oracle_vitb224()
+    ref_l, ref_b = o["f32_224"]["pred_logits"].numpy(), o["f32_224"]["pred_boxes"].numpy()
+    if precision in GATED:
+        e = [rel_err(got_l[:1], g["pred_logits"]), rel_err(got_b[:1], g["pred_boxes"]), rel_err(got_l, ref_l), rel_err(got_b, ref_b)]
+        print(f"timed config vitb224 B={B} {precision}: image 0 vs reference golden logits {e[0]:.2e} boxes {e[1]:.2e}; images 0-1 vs oracle {e[2]:.2e} {e[3]:.2e}"
+              f" (rel-L2 {rel_l2(got_l, ref_l):.2e} {rel_l2(got_b, ref_b):.2e})")
+        assert max(e) < TOL, e
+    else:
+        emu_l, emu_b = o["bf16_224"]["pred_logits"].numpy(), o["bf16_224"]["pred_boxes"].numpy()
+        el, eb, ol, ob = rel_l2(got_l, ref_l), rel_l2(got_b, ref_b), rel_l2(emu_l, ref_l), rel_l2(emu_b, ref_b)
+        print(f"timed config vitb224 B={B} bf16: rel-L2 vs fp32 oracle logits {el:.2e} (faithful emulation {ol:.2e}) boxes {eb:.2e} ({ob:.2e})")
+        assert el < K_BF16 * ol and eb < K_BF16 * ob
+    if precision == "fp32":
+        m.enable_hipgraph(False)
+        for i in (0, 1, B - 1):
+            assert torch.equal(m.forward_packed(x[i:i + 1])[0], det[i]), i
+    assert torch.equal(m.forward_packed(x) if precision != "fp32" else det, det)
+
+
 # ------------------------------------------------------------------------------------------------ the block GEMMs at M = 87 680
 M_BENCH = 64 * 1370
 SHAPES = [("qkv", 2304, 768, "none"), ("proj", 768, 768, "resid"), ("fc1", 3072, 768, "gelu"), ("fc2", 768, 3072, "resid")]
@@ -145,7 +193,11 @@ def _sample_rows(M):
     return torch.unique(idx)
 
 
-def _operands(name, N, K):
+M_CFG1 = 32 * 257       # BASELINE configs[1]: 32 images of 224x224 = 8 224 rows (198 tiles of 256x128: less than one round of 256 CUs)
+M_ROWS = [M_BENCH, M_CFG1]
+
+
+def _operands(name, N, K, M_BENCH=M_BENCH):
     g = torch.Generator(device="cuda").manual_seed(sum(map(ord, name)) * 7919 + N * 31 + K)
     A = torch.randn(M_BENCH, K, device="cuda", generator=g)
     W = torch.randn(N, K, device="cuda", generator=g) * 0.05
@@ -177,12 +229,13 @@ def _full_check(got, A, W, bias, scale, resid, epi, tol):
     assert err < tol, f"full-matrix check: {err:.3e}"
 
 
+@pytest.mark.parametrize("M_BENCH", M_ROWS)
 @pytest.mark.parametrize("name,N,K,epi", SHAPES, ids=[s[0] for s in SHAPES])
-def test_bench_shape_gemm_plain_bf16(name, N, K, epi):
+def test_bench_shape_gemm_plain_bf16(name, N, K, epi, M_BENCH):
     """the single-pass bf16 kernels bench.py's headline times (gemm_ppm_256x256<false>, gemm_x3_256x256<PLAIN>, 256x128_m16 for the
     GELU fc1; tail split by the shipped heuristic) against the exact product of the bf16-rounded operands"""
     L = nat.lib()
-    A, W, bias, scale, resid = _operands(name, N, K)
+    A, W, bias, scale, resid = _operands(name, N, K, M_BENCH)
     Ab, Wb = A.bfloat16(), W.bfloat16()
     rows = _sample_rows(M_BENCH)
     want = _want(Ab, Wb, bias, scale, resid, epi, rows.cuda()).numpy()
@@ -201,11 +254,12 @@ def test_bench_shape_gemm_plain_bf16(name, N, K, epi):
         assert rel_err(o32[rows.cuda()].cpu().numpy(), want) < (3e-6 if epi == "none" else 2e-5)      # GELU: the A&S erf of the bf16 path
 
 
+@pytest.mark.parametrize("M_BENCH", M_ROWS)
 @pytest.mark.parametrize("name,N,K,epi", SHAPES, ids=[s[0] for s in SHAPES])
-def test_bench_shape_gemm_split_product(name, N, K, epi):
+def test_bench_shape_gemm_split_product(name, N, K, epi, M_BENCH):
     """gemm_ppm_256x256<X3> / gemm_x3_256x256 (bf16x3 mode) at the timed shapes against the exact product of the fp32 inputs"""
     L = nat.lib()
-    A, W, bias, scale, resid = _operands(name, N, K)
+    A, W, bias, scale, resid = _operands(name, N, K, M_BENCH)
     A2, W2 = _pair(A), _pair(W)
     rows = _sample_rows(M_BENCH)
     want = _want(A, W, bias, scale, resid, epi, rows.cuda()).numpy()
@@ -222,11 +276,12 @@ def test_bench_shape_gemm_split_product(name, N, K, epi):
         _full_check(out[:, :N].float() + out[:, N:].float(), A, W, bias, scale, resid, epi, 2e-4)
 
 
+@pytest.mark.parametrize("M_BENCH", M_ROWS)
 @pytest.mark.parametrize("name,N,K,epi", SHAPES, ids=[s[0] for s in SHAPES])
-def test_bench_shape_gemm_h2(name, N, K, epi):
+def test_bench_shape_gemm_h2(name, N, K, epi, M_BENCH):
     """gemm_h2_256x256 (fp16x2 mode) at the timed shapes against the exact product of the fp32 inputs"""
     L = nat.lib()
-    A, W, bias, scale, resid = _operands(name, N, K)
+    A, W, bias, scale, resid = _operands(name, N, K, M_BENCH)
     Ab, _ = pack_h2(A)
     Wb, wexp = pack_h2(W, weight=True)
     rows = _sample_rows(M_BENCH)
@@ -247,3 +302,37 @@ def test_bench_shape_gemm_h2(name, N, K, epi):
         o = out[rows.cuda()].float().cpu()
         assert rel_err((o[:, :N] + o[:, N:]).numpy(), want) < 5e-5
         _full_check(out[:, :N].float() + out[:, N:].float(), A, W, bias, scale, resid, epi, 2e-4)
+
+
+# ------------------------------------------------------------------------------------------------ the decoder's query-side linears at B.Q = 3 200
+Q_ROWS = 32 * 100
+Q_SHAPES = [("in_proj", 2304, 768, "none"), ("attn_out", 768, 768, "resid"), ("linear1", 1024, 768, "relu"), ("linear2", 768, 1024, "resid"),
+            ("bbox0", 384, 768, "relu")]
+
+
+@pytest.mark.parametrize("name,N,K,epi", Q_SHAPES, ids=[s[0] for s in Q_SHAPES])
+def test_query_side_linears_at_cfg1_rows(name, N, K, epi):
+    """configs[1]'s decoder (deformable_attention.py:215-268 at B.Q = 32 x 100 rows): every query-side linear runs as ONE bf16 GEMM with
+    K' = 3K on [Ah | Ah | Al] x [Wh | Wl | Wh]^T through the small-grid rule (128x128 tiles for grids of a few dozen 256x128 tiles).
+    Against the exact fp64 product of the fp32 inputs: the split form is good to ~1e-5 (lo.lo dropped)."""
+    L = nat.lib()
+    g = torch.Generator(device="cuda").manual_seed(sum(map(ord, name)) * 131 + N + K)
+    A = torch.randn(Q_ROWS, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    bias = torch.randn(N, device="cuda", generator=g)
+    resid = torch.randn(Q_ROWS, N, device="cuda", generator=g)
+    Ah, Wh = A.bfloat16(), W.bfloat16()
+    Al, Wl = (A - Ah.float()).bfloat16(), (W - Wh.float()).bfloat16()
+    A3 = torch.cat([Ah, Ah, Al], 1).contiguous()
+    W3 = torch.cat([Wh, Wl, Wh], 1).contiguous()
+    want = A.double().cpu() @ W.double().cpu().t() + bias.double().cpu()
+    if epi == "relu":
+        want = want.clamp_min(0)
+    if epi == "resid":
+        want = want + resid.double().cpu()
+    out = torch.empty(Q_ROWS, N, device="cuda")
+    nat.check(L.dod_op_linear(1, nat.ptr(A3), 3 * K, nat.ptr(W3), 3 * K, Q_ROWS, N, 3 * K, nat.ptr(bias), None,
+                              nat.ptr(resid) if epi == "resid" else None, N, nat.ptr(out), 0, N, nat.ACT["relu" if epi == "relu" else "none"], nat.stream_ptr()))
+    err = rel_err(out.cpu().numpy(), want.numpy())
+    print(f"query-side {name} [{Q_ROWS} x {N} x 3*{K}]: {err:.2e} from fp64")
+    assert err < 3e-5
