@@ -1,9 +1,12 @@
 """Build libdinodet.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
-    python -m dinov2_od_amd._build [--force]
+    python -m dinov2_od_amd._build [--force] [--tuning]
 
 hipcc cross-compiles without a GPU.  Objects go to build/obj, the library to
 dinov2_od_amd/lib/libdinodet.so (git-ignored, but it travels with the gpurun snapshot).
+--tuning: the -DDINODET_TUNING build (in-kernel time stamps, register-only MFMA probes, tile / schedule overrides through
+DINODET_* variables: include/dinodet_tuning.h) -> lib/libdinodet_tuning.so, objects in build/obj_tuning; tools/ load it with
+DINODET_LIB=dinov2_od_amd/lib/libdinodet_tuning.so.  The release library has none of that.
 """
 import hashlib
 import os
@@ -19,7 +22,8 @@ LIB = os.path.join(LIBDIR, "libdinodet.so")
 OBJ = os.path.join(ROOT, "build", "obj")
 SOURCES = ["dod_api.hip", "gemm_bf16.hip", "gemm_f32.hip", "attn_bf16.hip", "attn_f32.hip", "rowops.hip", "deform.hip",
            "postproc.hip", "matchcost.hip", "gemm_fp8.hip", "attn_x3.hip", "gemm_x3.hip", "preproc.hip", "attn_f32m.hip", "gemm_pp.hip", "dec_train.hip", "patch_embed.hip"]
-HEADERS = [os.path.join(CSRC, "dod_common.h"), os.path.join(CSRC, "gemm_epi.h"), os.path.join(ROOT, "include", "dinodet.h")]
+HEADERS = [os.path.join(CSRC, "dod_common.h"), os.path.join(CSRC, "gemm_epi.h"), os.path.join(ROOT, "include", "dinodet.h"),
+           os.path.join(ROOT, "include", "dinodet_tuning.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include")]
 
@@ -47,11 +51,11 @@ def _digest(paths):
     return h.hexdigest()
 
 
-def _compile(src):
+def _compile(src, tuning=False):
     s = os.path.join(CSRC, src)
-    o = os.path.join(OBJ, src.replace(".hip", ".o"))
+    o = os.path.join(OBJ + ("_tuning" if tuning else ""), src.replace(".hip", ".o"))
     stamp = o + ".sha"
-    extra = EXTRA.get(src, [])
+    extra = EXTRA.get(src, []) + (["-DDINODET_TUNING"] if tuning else [])
     d = _digest([s] + HEADERS) + "|" + " ".join(extra)
     if os.path.exists(o) and os.path.exists(stamp) and open(stamp).read() == d:
         return o, False
@@ -66,14 +70,16 @@ def _compile(src):
     return o, True
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=True, tuning=False):
+    obj = OBJ + ("_tuning" if tuning else "")
+    LIB = os.path.join(LIBDIR, "libdinodet_tuning.so" if tuning else "libdinodet.so")
+    os.makedirs(obj, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     if force:
-        for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+        for f in os.listdir(obj):
+            os.remove(os.path.join(obj, f))
     with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
-        res = list(ex.map(_compile, SOURCES))
+        res = list(ex.map(lambda src: _compile(src, tuning), SOURCES))
     objs = [o for o, _ in res]
     if any(ch for _, ch in res) or not os.path.exists(LIB):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
@@ -88,4 +94,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, tuning="--tuning" in sys.argv)

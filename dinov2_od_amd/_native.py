@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdinodet.so")
+LIB_PATH = os.environ.get("DINODET_LIB") or os.path.join(_HERE, "lib", "libdinodet.so")      # DINODET_LIB: another build of the same ABI (A/B runs)
 
 DOD_F32, DOD_BF16 = 0, 1
 PREC = {"fp32": 0, "bf16": 1, "fp8": 2, "bf16x3": 3, "fp16x2": 4}
@@ -72,6 +72,20 @@ class DodBbTailParams(C.Structure):
                 ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p)]
 
 
+class DodLnFold(C.Structure):
+    """struct dod_ln_fold (include/dinodet.h): the folded-LayerNorm legs of dod_op_linear_ln"""
+    _fields_ = [("stats", C.c_void_p), ("csum", C.c_void_p), ("op_out", C.c_void_p), ("part", C.c_void_p)]
+
+
+# include/dinodet_tuning.h: exported by -DDINODET_TUNING builds only (tools/ load one through DINODET_LIB); bound when present
+TUNING_SYMBOLS = {
+    "dod_debug_gemm_stamps": (_I, [_P]),
+    "dod_debug_pp_stamps": (_I, [_P]),
+    "dod_debug_attn_stamps": (_I, [_P]),
+    "dod_debug_mfma_peak": (_I, [_I, _I, _I, _P, _P]),
+    "dod_debug_mfma_valu_probe": (_I, [_I, _I, _I, _I, _P, _P]),
+}
+
 # name -> (restype, argtypes): every symbol include/dinodet.h declares
 SYMBOLS = {
     "dod_create": (_I, [C.POINTER(DodConfig), C.POINTER(_P)]),
@@ -105,6 +119,9 @@ SYMBOLS = {
     "dod_op_split_h2": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "dod_op_linear_h2": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "dod_op_layernorm": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _I, _P]),
+    "dod_op_linear_ln": (_I, [_I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, C.POINTER(DodLnFold), _P]),
+    "dod_op_rowstats": (_I, [_P, _I, _I, _F, _P, _I, _P, _P]),
+    "dod_op_ln_finalize": (_I, [_P, _I, _I, _F, _P, _P]),
     "dod_op_attention_bf16": (_I, [_P, _P, _I, _I, _I, _F, _P]),
     "dod_op_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "dod_op_deform_sample": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
@@ -129,21 +146,15 @@ SYMBOLS = {
     "dod_backbone_tail_train_forward": (_I, [C.POINTER(DodConfig), _P, _P, _I, _I, _P, _P, _SZ, _P, _SZ, _P]),
     "dod_backbone_tail_train_backward": (_I, [C.POINTER(DodConfig), _P, _I, _I, _P, _P, _SZ, _P, _P, _SZ, _P]),
     "dod_reserve_gemm_scratch": (_I, [C.c_size_t]),
-    "dod_debug_tail_splits": (C.c_long, []),
-    "dod_debug_set_tailsplit": (None, [_I]),
-    "dod_debug_set_dec_fused_split": (None, [_I]),
-    "dod_debug_gemm_stamps": (_I, [_P]),
-    "dod_debug_pp_stamps": (_I, [_P]),
-    "dod_debug_attn_stamps": (_I, [_P]),
-    "dod_debug_mfma_peak": (_I, [_I, _I, _I, _P, _P]),
-    "dod_debug_mfma_valu_probe": (_I, [_I, _I, _I, _I, _P, _P]),
+    "dod_test_set_option": (_I, [C.c_char_p, _I]),
+    "dod_test_counter": (C.c_long, [C.c_char_p]),
     "dod_version": (C.c_char_p, []),
     "dod_abi_version": (_I, []),
     "dod_device_count": (_I, []),
 }
 
 _lib = None
-ABI_VERSION = 3     # include/dinodet.h DOD_ABI_VERSION
+ABI_VERSION = 4     # include/dinodet.h DOD_ABI_VERSION
 
 
 def lib():
@@ -160,11 +171,19 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
                 "Build it with `python -m dinov2_od_amd._build`.")
         L = C.CDLL(LIB_PATH)
+        other = bool(os.environ.get("DINODET_LIB"))      # an A/B build may be an earlier ABI revision: its missing entry points stay unbound
         for name, (res, args) in SYMBOLS.items():
+            if other and not hasattr(L, name):
+                continue
             fn = getattr(L, name)   # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if L.dod_abi_version() != ABI_VERSION:
+        for name, (res, args) in TUNING_SYMBOLS.items():
+            if hasattr(L, name):
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+        if L.dod_abi_version() != ABI_VERSION and not other:
             raise RuntimeError(f"{LIB_PATH} has ABI revision {L.dod_abi_version()}, this binding expects {ABI_VERSION}: rebuild it "
                                "(`python -m dinov2_od_amd._build --force`)")
         try:
@@ -175,6 +194,11 @@ def lib():
             pass
         _lib = L
     return _lib
+
+
+def set_option(name, value):
+    """dod_test_set_option (include/dinodet.h): a process-wide test option; -1 hands the shipped behaviour back"""
+    check(lib().dod_test_set_option(name.encode(), int(value)))
 
 
 class DodError(RuntimeError):

@@ -157,7 +157,12 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
 
 // tuning only (tools/attn_timeline.py): per workgroup {tile-loop cycles, cycles waiting for DMA + barrier, tiles, active,
 // s_memrealtime (100 MHz) at kernel entry, at the end of the tile loop}; the exit time is the next workgroup's entry
+#ifdef DINODET_TUNING
 __device__ unsigned long long* g_attn_stamps = nullptr;
+#define ATTN_STAMPS g_attn_stamps
+#else
+#define ATTN_STAMPS (static_cast<unsigned long long*>(nullptr))      // release build: the stamp code folds away
+#endif
 
 // K/V ring, [slot][K|V][64 rows][128 B] = 48 KiB: ONE file-scope array, so that both bodies of the fused kernel address the same
 // compile-time-constant LDS locations (a pointer parameter cost the 64-rows-per-wave body three registers and a spill)
@@ -170,7 +175,7 @@ __device__ __forceinline__ void attn_bf16_body(const int blk_, const bf16_t* __r
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int D = heads * 64, ld = 3 * D;
-  const unsigned long long rt_entry = g_attn_stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  const unsigned long long rt_entry = ATTN_STAMPS ? __builtin_amdgcn_s_memrealtime() : 0;
   // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs, so the q-blocks of one (image, head)
   // -- which all stream the same 350 KB of K/V -- are placed on ONE XCD (pair p -> XCD p % 8) and run back to back
   // there; with the plain (q-block, head, image) grid each XCD saw ~70 different pairs at once (24 MB of K/V
@@ -248,7 +253,7 @@ __device__ __forceinline__ void attn_bf16_body(const int blk_, const bf16_t* __r
   AT_STAGE(0, 0)
   if (nkt > 1) AT_STAGE(1, 1)
   int slot = 0;
-  unsigned long long* stamps = g_attn_stamps;
+  unsigned long long* stamps = ATTN_STAMPS;
   unsigned long long t_begin = 0, t_wait = 0;
   if (stamps) t_begin = __builtin_amdgcn_s_memtime();
   for (int kt = 0; kt < nkt; ++kt) {
@@ -312,10 +317,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fused_kernel(const bf16_t* _
   else attn_bf16_body<1>((int)blockIdx.x - main_blocks, qkv, ctx, N, heads, npairs, scale_log2e, q_main, N);
 }
 
+#ifdef DINODET_TUNING
 extern "C" int dod_debug_attn_stamps(void* dev_buf) {
   unsigned long long* p = (unsigned long long*)dev_buf;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 4;
 }
+#endif
 
 int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s) {
   if (B <= 0 || N <= 0 || heads <= 0) return 1;
@@ -323,17 +330,17 @@ int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, fl
   const float c = scale * 1.44269504088896340736f;
   // 64 query rows per wave once the grid still fills the chip several times over (measured: +5 % at B*heads = 768,
   // -12 % at 96), else 32
-  static const char* nqe = getenv("DINODET_ATTN_NQ");   // tuning override
+  static const char* nqe = DOD_TUNE_ENV("DINODET_ATTN_NQ");   // tuning override
   if (nqe ? nqe[0] == '2' : (long)npairs * ((N + 255) / 256) >= 4 * 256) {
     // A workgroup lasts as long as its busiest wave: the last 256-row block of N = 1370 (90 rows) keeps one wave fully busy and costs a
     // whole block time for a third of the rows.  When the remainder fits 128 rows it goes to a second launch of the 32-rows-per-wave
     // kernel (three waves with one q-block each: about half a block time): 5 + 0.55 instead of 6 block times per (image, head).
     const int rem = N % (AT_WAVES * 64);
-    static const char* tse = getenv("DINODET_ATTN_TAILSPLIT");
+    static const char* tse = DOD_TUNE_ENV("DINODET_ATTN_TAILSPLIT");
     const bool split = (tse ? tse[0] != '0' : true) && rem > 0 && rem <= AT_WAVES * 32 && N > AT_WAVES * 64;
     const int q_main = split ? N - rem : N;
     const int nqb = (q_main + AT_WAVES * 64 - 1) / (AT_WAVES * 64);
-    static const char* fse = getenv("DINODET_ATTN_FUSED_TAIL");      // "0": the two-launch form (A/B)
+    static const char* fse = DOD_TUNE_ENV("DINODET_ATTN_FUSED_TAIL");      // "0": the two-launch form (A/B)
     if (split && !(fse && fse[0] == '0')) {
       hipLaunchKernelGGL(attn_bf16_fused_kernel, dim3(pairs8 * nqb + pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, pairs8 * nqb, q_main);
     } else {

@@ -132,7 +132,7 @@ int launch_attn_f32_mfma(const AttnF32& a, hipStream_t s);   // attn_f32m.hip: h
 int launch_attn_f32(const AttnF32& a, hipStream_t s) {
   if (a.B <= 0 || a.heads <= 0 || a.Lq <= 0 || a.Lk <= 0) return 1;
   {
-    static const char* fm = getenv("DINODET_ATTN_F32_MFMA");     // "0": always the generic VALU kernel (A/B)
+    static const char* fm = DOD_TUNE_ENV("DINODET_ATTN_F32_MFMA");     // "0": always the generic VALU kernel (A/B)
     if ((a.lse || !fm || fm[0] != '0') && (a.dh == 32 || a.dh == 64 || a.dh == 96) && a.ldo % 4 == 0 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0)
       return launch_attn_f32_mfma(a, s);
   }

@@ -298,8 +298,8 @@ GemmF32X mha_gemm(const float* A, int lda, long long a_sb, long long a_sh, bool 
 // enough to keep the scores in the 256 MB Infinity Cache between launches were measured and do not pay: ViT-B 518x518, batch 8,
 // one image per pass 23.0 ms per step, two 22.0, the whole batch in one pass 21.7.
 inline int mha_chunk_images(int B, int Hd, int Lq, int Lk) {
-  const char* ei = getenv("DINODET_MHA_CHUNK_IMAGES");          // tests: force several (ragged) passes on small shapes
-  if (ei && atoi(ei) > 0) return atoi(ei) > B ? B : atoi(ei);
+  const int forced = dod_option(DOD_OPT_MHA_CHUNK_IMAGES);      // tests: force several (ragged) passes on small shapes
+  if (forced > 0) return forced > B ? B : forced;
   const char* e = getenv("DINODET_MHA_CHUNK_MB");
   const size_t mb = e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)1024;
   const size_t per = (size_t)Hd * Lq * up4((size_t)Lk) * 4;
@@ -541,7 +541,7 @@ GemmF32X xgemm(const float* A, int lda, bool a_km, const float* W, int ldw, bool
 // K slices for a product whose 64x64 tiles leave most of the chip idle (the decoder's 1 600-row linears: 300 tiles, a lone
 // workgroup's 16-k tile takes ~1 us): target ~768 workgroups of at least 8 k-tiles each; 1 = do not split
 int ksplit_for(int rows, int cols, int K) {
-  static const int target = [] { const char* e = getenv("DINODET_F32_KSPLIT_WGS"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
+  static const int target = [] { const char* e = DOD_TUNE_ENV("DINODET_F32_KSPLIT_WGS"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
   const int tiles = ((rows + 63) / 64) * ((cols + 63) / 64), nkt = (K + 15) / 16;
   if (tiles >= target) return 1;
   int ks = (target + tiles - 1) / tiles;

@@ -27,6 +27,9 @@ struct BLayer {
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
   float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
   bool glu = false;      // SwiGLU, bf16 / fp8 modes: W1 / b1 hold weights_in with the (x1_i, x2_i) rows INTERLEAVED; the gate runs in the GEMM epilogue
+  // folded LayerNorm (GemmEpi::ln_*): Wqkv / W1 hold W diag(gamma), bqkv / b1 hold b + W beta, cqkv / c1 the column sums of the packed rows
+  bool fold = false;
+  float *cqkv = nullptr, *c1 = nullptr;
 };
 struct DLayer {
   float *in_w = nullptr, *in_b = nullptr, *out_w = nullptr, *out_b = nullptr;
@@ -276,7 +279,7 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
     h->Kp = is_bf16(h) ? (K + 63) / 64 * 64 : K;
     if (W) h->Wpatch = P.pack_operand(W->ptr, D, K, h->Kp);
     h->Wpe = nullptr;
-    if (W && (is_bf16(h) || is_x3(h)) && (p == 14 || p == 16) && D % 4 == 0 && !getenv("DINODET_NO_FUSED_PATCH")) {
+    if (W && (is_bf16(h) || is_x3(h)) && (p == 14 || p == 16) && D % 4 == 0 && dod_option(DOD_OPT_NO_FUSED_PATCH) <= 0) {
       bf16_t* wp = P.alloc<bf16_t>((size_t)D * 3 * (p / 2) * 32 * (is_x3(h) ? 2 : 1));
       if (wp && !launch_patch_pack(W->ptr, D, p, wp, is_x3(h) ? 1 : 0, s)) h->Wpe = wp;
     }
@@ -308,6 +311,29 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
     }
     if (P.rc) break;
     const bool f8 = is_fp8(h), h2 = is_h2(h), x3 = is_x3(h) && !h2;
+    // norm1 / norm2 folded into the QKV / MLP-in GEMMs (bf16 and the compensated modes; the strict fp32 and the fp8 schedule keep the LayerNorm
+    // kernel): W' = W diag(gamma), b' = b + W beta, c = row sums of what the MFMAs multiply.  DINODET_LN_FOLD=0 (or the test option): the
+    // round-3 schedule.
+    static const bool fold_env = [] { const char* v = getenv("DINODET_LN_FOLD"); return v && v[0] == '1'; }();      // (off until it pays: r4_exp1)
+    const int fold_opt = dod_option(DOD_OPT_LN_FOLD);
+    L.fold = (fold_opt >= 0 ? fold_opt != 0 : fold_env) && !f8 && (is_bf16(h) || is_x3(h)) && D % 32 == 0;
+    auto fold_ln = [&](const float* w, int rows, const float* gamma, const float* beta, float* bias) -> float* {      // -> folded fp32 copy (temporary)
+      float* wf = P.alloc<float>((size_t)rows * D, true);
+      if (!w || !wf || !gamma || !beta || !bias) return nullptr;
+      if (launch_ln_fold(w, rows, D, gamma, beta, bias, wf, bias, s)) { if (!P.rc) P.rc = fail(h, DOD_ERR_HIP, "LayerNorm fold launch failed"); return nullptr; }
+      return wf;
+    };
+    auto col_sums = [&](const float* wf, int rows) -> float* {
+      float* cs = P.alloc<float>((size_t)rows);
+      if (!wf || !cs) return nullptr;
+      if (launch_rowsum(wf, rows, D, (is_bf16(h) && !is_x3(h)) ? 1 : 0, cs, s)) { if (!P.rc) P.rc = fail(h, DOD_ERR_HIP, "row sum launch failed"); return nullptr; }
+      return cs;
+    };
+    if (L.fold) {
+      float* cf = fold_ln(cat, 3 * D, L.ln1w, L.ln1b, L.bqkv);
+      if (cf) { cat = cf; L.cqkv = col_sums(cat, 3 * D); }
+      if (!cf || !L.cqkv) { if (!P.rc) P.rc = fail(h, DOD_ERR_HIP, "LayerNorm fold failed"); break; }
+    }
     // one block linear in the precision's operand format: H2 rows + exponent bytes (fp16x2), pair layout (bf16x3), e4m3 + row scales
     // (fp8; GELU-MLP fc2 stays bf16), else bf16 / fp32
     auto packw = [&](const float* w, int rows, int cols, float** sc, unsigned char** ex, bool fp8_ok) -> void* {
@@ -325,25 +351,30 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
       // bf16 / fp8 operands: hidden = silu(x1) * x2 (modeling_dinov2.py:310-314) is evaluated in the weights_in GEMM's epilogue
       // (GemmEpi::glu) on interleaved column pairs -- rows of the weight and the bias re-ordered once here (x1_i, x2_i adjacent; the
       // fp8 per-feature scales are computed on the re-ordered rows).  The compensated and fp32 modes keep the separate gate kernel.
-      static const bool glu_off = getenv("DINODET_NO_FUSED_GLU") != nullptr;
+      static const bool glu_off = DOD_TUNE_ENV("DINODET_NO_FUSED_GLU") != nullptr;
       // (round 3b: the compensated modes too -- their gate was three passes over fp32 [M, 2F] / [M, F] buffers: 4.9 GB per ViT-g block at 32
       // images; the epilogue now writes the pair / H2 operand rows of weights_out directly.  H2 rows need F % 32 == 0 and whole quads.)
       const bool glu_ok = is_x3(h) ? (F % 32 == 0) : is_bf16(h);
+      if (L.fold) w_in = fold_ln(w_in, 2 * F, L.ln2w, L.ln2b, L.b1);
       if (w_in && L.b1 && glu_ok && !glu_off) {
         float* wi = P.alloc<float>((size_t)2 * F * D, true);
         float* bi = P.alloc<float>((size_t)2 * F);
         if (wi && bi && !launch_interleave_halves(w_in, wi, F, D, s) && !launch_interleave_halves(L.b1, bi, F, 1, s)) { w_in = wi; L.b1 = bi; L.glu = true; }
       }
+      if (L.fold) L.c1 = col_sums(w_in, 2 * F);
       L.W1 = packw(w_in, 2 * F, D, &L.s1, &L.e1, true);
       L.W2 = packw(P.eff_weight(lp + "mlp.weights_out", D, F), D, F, &L.s2, &L.e2, true);
       L.b2 = P.eff_bias(lp + "mlp.weights_out", D);
     } else {
-      L.W1 = packw(P.eff_weight(lp + "mlp.fc1", F, D), F, D, &L.s1, &L.e1, true);
+      const float* w1 = P.eff_weight(lp + "mlp.fc1", F, D);
       L.b1 = P.eff_bias(lp + "mlp.fc1", F);
+      if (L.fold) { w1 = fold_ln(w1, F, L.ln2w, L.ln2b, L.b1); L.c1 = col_sums(w1, F); }
+      L.W1 = packw(w1, F, D, &L.s1, &L.e1, true);
       L.W2 = packw(P.eff_weight(lp + "mlp.fc2", D, F), D, F, &L.s2, &L.e2, false);
       L.b2 = P.eff_bias(lp + "mlp.fc2", D);
     }
   }
+  if (!P.rc) for (auto& L : h->L) if (L.fold && (!L.cqkv || !L.c1 || !L.W1)) { P.rc = fail(h, DOD_ERR_HIP, "LayerNorm fold failed"); break; }
   if (P.rc) goto done;
   h->lnfw = P.copy(bb + "layernorm.weight", {D}); h->lnfb = P.copy(bb + "layernorm.bias", {D});
   if (c.target_dim) {
@@ -438,16 +469,13 @@ struct Carver {
   void* take(size_t bytes) { void* p = base ? base + off : nullptr; off += align_up(bytes); return p; }
 };
 
-// -1: DINODET_DEC_FUSED_SPLIT from the environment (default on); 0 / 1: forced (tests)
-static std::atomic<int> g_dec_fused_split{-1};
-extern "C" void dod_debug_set_dec_fused_split(int mode) { g_dec_fused_split.store(mode); }
 // the real carve must fit what the sizing pass (a carve from a null base) reported: a buffer taken only when another POINTER is non-null
 // is invisible to the sizing pass -- fail loudly instead of writing past the caller's workspace
 #define CARVE_FITS(h, c, workspace, wsb)                                                                                      \
   if ((size_t)((c).base - (char*)(workspace)) + (c).off > (wsb))                                                              \
     return fail(h, DOD_ERR_STATE, "internal: workspace carve %zu exceeds the %zu bytes provided", (size_t)((c).base - (char*)(workspace)) + (c).off, (size_t)(wsb));
 struct DecWS { float *tgt, *t2, *att, *samp, *qkv, *proj, *ffn, *hb, *qd; void* mem_op; float* values; float* kv; bf16_t* a3; bf16_t* a3b; bf16_t* mem2; };   // mem2: bf16x3 mode, memory in the pair layout [M, 2*Dd]
-struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; float* rs; unsigned char* bs; };   // rs: fp8 mode, per-row activation scales [M]
+struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; float* rs; unsigned char* bs; float2 *lnp, *lns; };   // rs: fp8 mode, per-row activation scales [M]; lnp / lns: folded LayerNorm group / row statistics
 
 size_t carve_decoder(const dod_handle* h, Carver& c, int B, int N, DecWS* w, bool need_mem_op) {
   const dod_config& g = h->cfg;
@@ -487,6 +515,9 @@ size_t carve_backbone(const dod_handle* h, Carver& c, int B, int N, BbWS* w) {
   t.mem = c.take(M * (size_t)(g.target_dim ? g.target_dim : g.hidden) * es);
   t.rs = is_fp8(h) ? (float*)c.take(M * 4) : nullptr;
   t.bs = (is_fp8(h) && g.swiglu && g.ffn_hidden % 256 == 0) ? (unsigned char*)c.take(M * (size_t)(g.ffn_hidden / 32)) : nullptr;     // e8m0 block scales of the gated rows
+  const bool foldable = !is_fp8(h) && (is_bf16(h) || is_x3(h)) && D % 32 == 0;      // (not "L.fold": the sizing pass may run before finalize)
+  t.lnp = foldable ? (float2*)c.take(M * ((D + 127) / 128) * 8) : nullptr;
+  t.lns = foldable ? (float2*)c.take(M * 8) : nullptr;
   if (w) *w = t;
   return c.off;
 }
@@ -595,13 +626,31 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   const float scale = 1.0f / std::sqrt((float)(D / g.heads));
   float* yf = bf ? nullptr : (float*)ws.y; bf16_t* yb = bf ? (bf16_t*)ws.y : nullptr;
   const bool f8 = is_fp8(h);   // LayerNorm / SwiGLU emit e4m3 rows + per-row scales (ws.rs) for the QKV / MLP linears
-  // fp8 SwiGLU: block-scaled gated rows written by the weights_in epilogue (F % 256 == 0; DINODET_FP8_MX_GATE=0: bf16 rows + a quantisation pass)
-  static const bool mx_gate_env = [] { const char* v = getenv("DINODET_FP8_MX_GATE"); return !(v && v[0] == '0'); }();
+  // fp8 SwiGLU: block-scaled gated rows written by the weights_in epilogue (F % 256 == 0; tuning builds, DINODET_FP8_MX_GATE=0: bf16 rows + a quantisation pass)
+  static const bool mx_gate_env = [] { const char* v = DOD_TUNE_ENV("DINODET_FP8_MX_GATE"); return !(v && v[0] == '0'); }();
   const bool mx_gate = mx_gate_env && g.ffn_hidden % 256 == 0;
   const bool x3 = is_x3(h);
   const int nblocks = stop_blocks >= 0 ? (stop_blocks < g.layers ? stop_blocks : g.layers) : g.layers;
+  // Folded LayerNorm (BLayer::fold; modeling_dinov2.py:361-380): no norm1 / norm2 pass.  ws.y always holds the CURRENT residual rows in the
+  // operand format (written by rowstats for block 0, then by the out-proj / fc2 epilogues), ws.lns their (mean, rstd).
+  const bool fold = !h->L.empty() && h->L[0].fold && ws.lnp && ws.lns;
+  const int op_kind = is_h2(h) ? LNOP_H2 : (x3 ? LNOP_PAIR : LNOP_BF16);
+  const int npart = (D + 127) / 128;
+  auto ln_producer = [&](GemmEpi e, bool wanted) {      // residual epilogue: + operand copy of the new rows + their group statistics
+    if (fold && wanted) { e.ln_op = ws.y; e.ln_op_kind = op_kind; e.ln_op_ld = (op_kind == LNOP_BF16 ? D : 2 * D); e.ln_part = ws.lnp; e.ln_npart = npart; }
+    return e;
+  };
+  auto ln_consumer = [&](GemmEpi e, const float* csum) { if (fold) { e.ln_stats = ws.lns; e.ln_c = csum; } return e; };
+  auto ln_merge = [&](bool wanted) -> int {
+    if (!fold || !wanted) return 0;
+    ProfScope ps(h, s, PC_LAYERNORM, 0);
+    KCHK(h, launch_ln_finalize(ws.lnp, npart, M, D, g.ln_eps, ws.lns, s));
+    return 0;
+  };
+  if (fold && nblocks > 0) { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_rowstats(ws.x, M, D, g.ln_eps, ws.y, op_kind, ws.lns, s)); }
   for (int i = 0; i < nblocks; ++i) {
     const BLayer& L = h->L[i];
+    const bool more = i + 1 < g.layers;      // another block reads the residual after this one (the final LayerNorm is a kernel of its own)
     if (x3) {   // bf16x3 / fp16x2: every block linear as a compensated product on the bf16 / fp16+e4m3 kernels; attention and LayerNorm in fp32
       const bool h2 = is_h2(h);
       bf16_t* y3 = (bf16_t*)ws.y;       // pair layout [hi | lo] (bf16x3) or H2 rows (fp16x2): 4 bytes per element either way
@@ -611,15 +660,15 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
       auto split = [&](const float* src, int cols, void* dst) -> int {
         return h2 ? launch_split_h2(src, cols, dst, M, cols, nullptr, s) : launch_split2(src, cols, (bf16_t*)dst, M, cols, s);
       };
-      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3, h2 ? 1 : 0)); }
+      if (!fold) { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3, h2 ? 1 : 0)); }
       if (D / g.heads == 64) {   // split-product flash attention on the bf16 MFMA cores (both modes: its q / k / v stay bf16 pairs)
         GemmEpi eq = epi(L.bqkv, nullptr, ws.qkv, 6 * D);
         eq.out_split = -3 * D;       // [hi(q|k|v) | lo(q|k|v)]
-        rc = lin(y3, L.Wqkv, L.eqkv, 3 * D, D, eq); if (rc) return rc;
+        rc = lin(y3, L.Wqkv, L.eqkv, 3 * D, D, ln_consumer(eq, L.cqkv)); if (rc) return rc;
         ProfScope ps(h, s, PC_ATTN_BF16, 4.0 * B * (double)N * N * D);
         KCHK(h, launch_attn_x3((const bf16_t*)ws.qkv, (bf16_t*)ws.ctx, B, N, g.heads, scale, s, h2 ? 1 : 0));
       } else {                    // other head sizes (micro test models): generic fp32 attention, then split
-        rc = lin(y3, L.Wqkv, L.eqkv, 3 * D, D, epi(L.bqkv, (float*)ws.qkv, nullptr, 3 * D)); if (rc) return rc;
+        rc = lin(y3, L.Wqkv, L.eqkv, 3 * D, D, ln_consumer(epi(L.bqkv, (float*)ws.qkv, nullptr, 3 * D), L.cqkv)); if (rc) return rc;
         float* ctxf = (float*)ws.hbuf;
         {
           ProfScope ps(h, s, PC_ATTN_F32, 4.0 * B * (double)N * N * D);
@@ -630,23 +679,25 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
         }
         KCHK(h, split(ctxf, D, ws.ctx));
       }
-      rc = lin(ws.ctx, L.Wo, L.eo, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D)); if (rc) return rc;
-      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3, h2 ? 1 : 0)); }
+      rc = lin(ws.ctx, L.Wo, L.eo, D, D, ln_producer(epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), true)); if (rc) return rc;
+      if (!fold) { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, nullptr, nullptr, y3, h2 ? 1 : 0)); }
+      rc = ln_merge(true); if (rc) return rc;
       if (g.swiglu && L.glu) {      // gate in the weights_in epilogue, written as the pair / H2 operand rows of weights_out
         GemmEpi e1 = epi(L.b1, nullptr, ws.hbuf, 2 * F); e1.glu = 1;
         if (h2) e1.out_h2 = 1; else e1.out_split = -F;
-        rc = lin(y3, L.W1, L.e1, 2 * F, D, e1); if (rc) return rc;
+        rc = lin(y3, L.W1, L.e1, 2 * F, D, ln_consumer(e1, L.c1)); if (rc) return rc;
       } else if (g.swiglu) {
-        rc = lin(y3, L.W1, L.e1, 2 * F, D, epi(L.b1, (float*)ws.hbuf, nullptr, 2 * F)); if (rc) return rc;
+        rc = lin(y3, L.W1, L.e1, 2 * F, D, ln_consumer(epi(L.b1, (float*)ws.hbuf, nullptr, 2 * F), L.c1)); if (rc) return rc;
         KCHK(h, launch_swiglu((const float*)ws.hbuf, nullptr, M, F, (float*)ws.gated, nullptr, s));
         KCHK(h, split((const float*)ws.gated, F, ws.hbuf));
       } else {
         GemmEpi e1 = epi(L.b1, nullptr, ws.hbuf, 2 * F, ACT_GELU);
         if (h2) e1.out_h2 = 1;        // H2 rows
         else e1.out_split = -F;       // pair layout [hi | lo]
-        rc = lin(y3, L.W1, L.e1, F, D, e1); if (rc) return rc;
+        rc = lin(y3, L.W1, L.e1, F, D, ln_consumer(e1, L.c1)); if (rc) return rc;
       }
-      rc = lin(ws.hbuf, L.W2, L.e2, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D)); if (rc) return rc;
+      rc = lin(ws.hbuf, L.W2, L.e2, D, F, ln_producer(epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), more)); if (rc) return rc;
+      rc = ln_merge(more); if (rc) return rc;
       tap(h, 1 + i, ws.x, false, (size_t)M * D, s);
       continue;
     }
@@ -654,8 +705,8 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
       { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, nullptr, nullptr, s, (unsigned char*)ws.y, ws.rs)); }
       rc = linear8(h, ws.y, ws.rs, L.Wqkv, L.sqkv, M, 3 * D, D, epi(L.bqkv, nullptr, ws.qkv, 3 * D), s); if (rc) return rc;
     } else {
-      { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, yf, yb, s)); }   // K3
-      rc = linear(h, bf, ws.y, D, L.Wqkv, D, M, 3 * D, D, epi(L.bqkv, bf ? nullptr : (float*)ws.qkv, bf ? ws.qkv : nullptr, 3 * D), s); if (rc) return rc;  // K4
+      if (!fold) { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln1w, L.ln1b, g.ln_eps, M, D, yf, yb, s)); }   // K3
+      rc = linear(h, bf, ws.y, D, L.Wqkv, D, M, 3 * D, D, ln_consumer(epi(L.bqkv, bf ? nullptr : (float*)ws.qkv, bf ? ws.qkv : nullptr, 3 * D), L.cqkv), s); if (rc) return rc;  // K4
     }
     if (bf) { ProfScope ps(h, s, PC_ATTN_BF16, 4.0 * B * (double)N * N * D); KCHK(h, launch_attn_bf16((const bf16_t*)ws.qkv, (bf16_t*)ws.ctx, B, N, g.heads, scale, s)); }    // K5
     else {
@@ -669,7 +720,8 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
       KCHK(h, launch_quant_rows_fp8(ws.ctx, 1, D, M, D, (unsigned char*)ws.y, D, ws.rs, s));
       rc = linear8(h, ws.y, ws.rs, L.Wo, L.so, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;
     } else {
-      rc = linear(h, bf, ws.ctx, D, L.Wo, D, M, D, D, epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), s); if (rc) return rc;   // K6
+      rc = linear(h, bf, ws.ctx, D, L.Wo, D, M, D, D, ln_producer(epi(L.bo, ws.x, nullptr, D, ACT_NONE, L.ls1, ws.x, D), true), s); if (rc) return rc;   // K6
+      rc = ln_merge(true); if (rc) return rc;
     }
     if (f8) {
       { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, nullptr, nullptr, s, (unsigned char*)ws.y, ws.rs)); }
@@ -696,19 +748,20 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
       tap(h, 1 + i, ws.x, false, (size_t)M * D, s);
       continue;
     }
-    { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, yf, yb, s)); }
+    if (!fold) { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_layernorm(ws.x, nullptr, L.ln2w, L.ln2b, g.ln_eps, M, D, yf, yb, s)); }
     if (g.swiglu && L.glu && bf) {                                                                             // K7g, gate in the epilogue
       GemmEpi eg = epi(L.b1, nullptr, ws.gated, F); eg.glu = 1;
-      rc = linear(h, true, ws.y, D, L.W1, D, M, 2 * F, D, eg, s); if (rc) return rc;
-      rc = linear(h, true, ws.gated, F, L.W2, F, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
+      rc = linear(h, true, ws.y, D, L.W1, D, M, 2 * F, D, ln_consumer(eg, L.c1), s); if (rc) return rc;
+      rc = linear(h, true, ws.gated, F, L.W2, F, M, D, F, ln_producer(epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), more), s); if (rc) return rc;
     } else if (g.swiglu) {                                                                                     // K7g
-      rc = linear(h, bf, ws.y, D, L.W1, D, M, 2 * F, D, epi(L.b1, bf ? nullptr : (float*)ws.hbuf, bf ? ws.hbuf : nullptr, 2 * F), s); if (rc) return rc;
+      rc = linear(h, bf, ws.y, D, L.W1, D, M, 2 * F, D, ln_consumer(epi(L.b1, bf ? nullptr : (float*)ws.hbuf, bf ? ws.hbuf : nullptr, 2 * F), L.c1), s); if (rc) return rc;
       KCHK(h, launch_swiglu(bf ? nullptr : (const float*)ws.hbuf, bf ? (const bf16_t*)ws.hbuf : nullptr, M, F, bf ? nullptr : (float*)ws.gated, bf ? (bf16_t*)ws.gated : nullptr, s));
-      rc = linear(h, bf, ws.gated, F, L.W2, F, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
+      rc = linear(h, bf, ws.gated, F, L.W2, F, M, D, F, ln_producer(epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), more), s); if (rc) return rc;
     } else {                                                                                                   // K7
-      rc = linear(h, bf, ws.y, D, L.W1, D, M, F, D, epi(L.b1, bf ? nullptr : (float*)ws.hbuf, bf ? ws.hbuf : nullptr, F, ACT_GELU), s); if (rc) return rc;
-      rc = linear(h, bf, ws.hbuf, F, L.W2, F, M, D, F, epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), s); if (rc) return rc;
+      rc = linear(h, bf, ws.y, D, L.W1, D, M, F, D, ln_consumer(epi(L.b1, bf ? nullptr : (float*)ws.hbuf, bf ? ws.hbuf : nullptr, F, ACT_GELU), L.c1), s); if (rc) return rc;
+      rc = linear(h, bf, ws.hbuf, F, L.W2, F, M, D, F, ln_producer(epi(L.b2, ws.x, nullptr, D, ACT_NONE, L.ls2, ws.x, D), more), s); if (rc) return rc;
     }
+    rc = ln_merge(more); if (rc) return rc;
     tap(h, 1 + i, ws.x, false, (size_t)M * D, s);
   }
   if (stop_blocks >= 0) {
@@ -767,12 +820,10 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
   }
   const float sscale = 1.0f / std::sqrt((float)dh);
   // query-side linear: fp32 MFMA kernel, or (bf16 mode, large enough, N % 4 == 0) the bf16x3-split form on the bf16 kernel
-  static const int qrows = getenv("DINODET_QSPLIT_ROWS") ? atoi(getenv("DINODET_QSPLIT_ROWS")) : 1024;   // tuning
-  // DINODET_DEC_FUSED_SPLIT=0 / dod_debug_set_dec_fused_split(0): every query-side linear splits its own operand with a split3 launch
-  // (the round-2 schedule; A/B and the bit-identity test)
-  static const bool fuse3_env = [] { const char* v = getenv("DINODET_DEC_FUSED_SPLIT"); return !(v && v[0] == '0'); }();
-  const int f3m = g_dec_fused_split.load();
-  const bool fuse3 = f3m < 0 ? fuse3_env : f3m != 0;
+  static const int qrows = DOD_TUNE_ENV("DINODET_QSPLIT_ROWS") ? atoi(DOD_TUNE_ENV("DINODET_QSPLIT_ROWS")) : 1024;
+  // test option DOD_OPT_DEC_FUSED_SPLIT = 0: every query-side linear splits its own operand with a split3 launch (the round-2 schedule: the
+  // bit-identity test)
+  const bool fuse3 = dod_option(DOD_OPT_DEC_FUSED_SPLIT) != 0;
   // will this linear take the split form?  (then its producer writes the [hi | hi | lo] operand itself -- LayerNorm, the attention and
   // sampling kernels, the ReLU epilogue -- instead of a split3 launch over its fp32 output: 15 launches per forward)
   auto splits = [&](const bf16_t* W3, int rows, int Nout, int ldc, int act) {
@@ -898,7 +949,23 @@ int launch_widen_bf16(const bf16_t* in, float* out, size_t n, hipStream_t s) {
 }
 
 // =========================================================================================== C ABI
+// ---- test hooks (dod_common.h DOD_OPT_*)
+static std::atomic<int> g_options[DOD_OPT_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+int dod_option(int which) { return which >= 0 && which < DOD_OPT_COUNT ? g_options[which].load() : -1; }
+static const char* const k_option_names[DOD_OPT_COUNT] = {"tailsplit", "dec_fused_split", "mha_chunk_images", "no_fused_patch", "ln_fold", "deterministic"};
+
 extern "C" {
+
+int dod_test_set_option(const char* name, int value) {
+  if (!name) return fail(nullptr, DOD_ERR_INVALID, "null option name");
+  for (int i = 0; i < DOD_OPT_COUNT; ++i)
+    if (!strcmp(name, k_option_names[i])) { g_options[i].store(value); return DOD_OK; }
+  return fail(nullptr, DOD_ERR_INVALID, "unknown test option '%s'", name);
+}
+long dod_test_counter(const char* name) {
+  if (name && !strcmp(name, "tail_splits")) return gemm_tail_split_count();
+  return -1;
+}
 
 const char* dod_version(void) { return "dinodet 0.3 (gfx950)"; }
 int dod_abi_version(void) { return DOD_ABI_VERSION; }
@@ -1000,8 +1067,8 @@ static void* align_ws(void* p) { return (void*)(((uintptr_t)p + 255) & ~(uintptr
 
 static int split_setup(dod_handle* h) {
   if (h->nsplit < 0) {
-    const char* e = getenv("DINODET_STREAMS");
-    h->nsplit = e ? atoi(e) : 1;   // opt-in (DINODET_STREAMS=2): measured +3 % on the round-1 kernels, 0 % on the current ones
+    const char* e = DOD_TUNE_ENV("DINODET_STREAMS");
+    h->nsplit = e ? atoi(e) : 1;   // tuning builds (DINODET_STREAMS=2): measured +3 % on the round-1 kernels, 0 % on the current ones (the engine's micro-batches superseded it)
     if (h->nsplit != 2) h->nsplit = 1;
   }
   if (h->nsplit == 2 && !h->side[0]) {
@@ -1228,6 +1295,47 @@ int dod_op_linear_h2(const void* A, const void* W, const void* wexp, int M, int 
   e.h2_wexp = (const unsigned char*)wexp;
   int r = launch_gemm_h2(A, 4 * K, W, 3 * K, M, N, K, e, (hipStream_t)stream);
   if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear_h2 rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
+  return DOD_OK;
+}
+// Block linears with the LayerNorm folded into them (GemmEpi::ln_*): family = DOD_PREC_BF16 / DOD_PREC_BF16X3 / DOD_PREC_FP16X2 picks the operand
+// format (and the kernel family) exactly as the forward does
+int dod_op_linear_ln(int family, const void* A, const void* W, const void* wexp, int M, int N, int K, const float* bias, const float* scale,
+                     const float* resid, int ldr, void* out, int out_layout, int ldc, int act, const dod_ln_fold* ln, void* stream) {
+  if (!A || !W || !out || !ln) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  if (family != DOD_PREC_BF16 && family != DOD_PREC_BF16X3 && family != DOD_PREC_FP16X2) return fail(nullptr, DOD_ERR_INVALID, "family must be a bf16 / bf16x3 / fp16x2 precision");
+  if ((ln->stats == nullptr) != (ln->csum == nullptr)) return fail(nullptr, DOD_ERR_INVALID, "stats and csum go together");
+  if (ln->stats && scale) return fail(nullptr, DOD_ERR_INVALID, "the folded consumer has no LayerScale");
+  if (ln->part && !(resid && out_layout == 0)) return fail(nullptr, DOD_ERR_INVALID, "the folded producer is the fp32 residual epilogue");
+  GemmEpi e = epi(bias, out_layout == 0 ? (float*)out : nullptr, out_layout != 0 ? out : nullptr, ldc, act, scale, resid, ldr);
+  if (out_layout == 2) e.out_split = -N;
+  if (out_layout == 3) e.out_h2 = 1;
+  e.ln_stats = (const float2*)ln->stats; e.ln_c = ln->csum;
+  if (ln->part) {
+    e.ln_part = (float2*)ln->part; e.ln_npart = (N + 127) / 128; e.ln_op = ln->op_out;
+    e.ln_op_kind = family == DOD_PREC_FP16X2 ? LNOP_H2 : (family == DOD_PREC_BF16X3 ? LNOP_PAIR : LNOP_BF16);
+    e.ln_op_ld = family == DOD_PREC_BF16 ? N : 2 * N;
+  }
+  int r;
+  if (family == DOD_PREC_FP16X2) {
+    if (!wexp) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+    e.h2_wexp = (const unsigned char*)wexp;
+    r = launch_gemm_h2(A, 4 * K, W, 3 * K, M, N, K, e, (hipStream_t)stream);
+  } else if (family == DOD_PREC_BF16X3) r = launch_gemm_x3((const bf16_t*)A, 2 * K, (const bf16_t*)W, 2 * K, M, N, K, e, (hipStream_t)stream);
+  else r = launch_gemm_bf16((const bf16_t*)A, K, (const bf16_t*)W, K, M, N, K, e, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_linear_ln rejected M=%d N=%d K=%d (rc %d)", M, N, K, r);
+  return DOD_OK;
+}
+int dod_op_rowstats(const float* x, int rows, int D, float eps, void* op_out, int family, void* stats, void* stream) {
+  if (!x || !op_out || !stats) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  const int kind = family == DOD_PREC_FP16X2 ? LNOP_H2 : (family == DOD_PREC_BF16X3 ? LNOP_PAIR : (family == DOD_PREC_BF16 ? LNOP_BF16 : 0));
+  int r = launch_rowstats(x, rows, D, eps, op_out, kind, (float2*)stats, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_rowstats rejected rows=%d D=%d", rows, D);
+  return DOD_OK;
+}
+int dod_op_ln_finalize(const void* part, int rows, int D, float eps, void* stats, void* stream) {
+  if (!part || !stats) return fail(nullptr, DOD_ERR_INVALID, "null buffer");
+  int r = launch_ln_finalize((const float2*)part, (D + 127) / 128, rows, D, eps, (float2*)stats, (hipStream_t)stream);
+  if (r) return fail(nullptr, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "dod_op_ln_finalize rejected rows=%d D=%d", rows, D);
   return DOD_OK;
 }
 int dod_op_attention_x3(const void* qkv2, void* ctx2, int B, int N, int heads, float scale, void* stream) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -12,6 +13,27 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef unsigned short bf16_t;   // storage type of bf16 in memory
 
 #define DOD_WAVE 64
+
+// Tuning switches (tile overrides, A/B schedules, in-kernel time stamps, the register-only MFMA probes) exist only in -DDINODET_TUNING builds
+// (`python -m dinov2_od_amd._build --tuning` -> lib/libdinodet_tuning.so, which tools/ load through DINODET_LIB).  The release library reads
+// the few OPERATIONAL variables INTEGRATION.md lists and nothing else: no environment variable can change which kernel runs or what it computes.
+// Test hooks (extern "C" dod_test_set_option(name, value), include/dinodet.h): process-wide integer options a parity test sets for its own cases
+// and hands back (-1 = the shipped behaviour).  Not environment variables: nothing outside the calling process can flip them.
+enum { DOD_OPT_TAILSPLIT = 0,         // GEMM wave-quantisation tail split: 0 off, 1 shipped heuristic, 2 every qualifying shape
+       DOD_OPT_DEC_FUSED_SPLIT,       // decoder split operands written by their producers: 0 = a split3 launch per linear (round-2 schedule)
+       DOD_OPT_MHA_CHUNK_IMAGES,      // training-step attention: images per pass (forces several ragged passes on small shapes)
+       DOD_OPT_NO_FUSED_PATCH,        // 1 = pack for the explicit im2col + GEMM patch embedding instead of the fused kernel (read at dod_finalize_weights)
+       DOD_OPT_LN_FOLD,               // 0 = LayerNorm kernels instead of the folded form (read at dod_finalize_weights)
+       DOD_OPT_DETERMINISTIC,         // 1 = ordered reductions instead of fp32 atomics in the training step's weight gradients
+       DOD_OPT_COUNT };
+int dod_option(int which);            // dod_api.hip; -1 when unset
+long gemm_tail_split_count();         // gemm_pp.hip: GEMM calls that took the tail-split path so far
+
+#ifdef DINODET_TUNING
+#define DOD_TUNE_ENV(name) getenv(name)
+#else
+#define DOD_TUNE_ENV(name) (static_cast<const char*>(nullptr))
+#endif
 
 __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;   // v_cvt_pk_bf16_f32: RNE, NaN preserved
@@ -140,11 +162,24 @@ struct GemmEpi {
   int ksplit;             // ping-pong / H2 kernels only: > 1 = the grid's y index is a K slice of kslice_len k; the slice's fp32 partial
   int kslice_len;         //   product goes to out_f32 + slice * kslice_stride (no other epilogue term may be set)
   long long kslice_stride;
-  int rb;                 // residual epilogue of the 512-thread 256x256 kernels: residual loads in flight per thread (0 = 4; 8, 16)
   int glu;                // with out_bf16 (plain layout): the GEMM's columns are INTERLEAVED SwiGLU pairs (2i: x1_i, 2i + 1: x2_i;
                           //   Dinov2SwiGLUFFN, modeling_dinov2.py:310-314) and the epilogue writes silu(x1_i) * x2_i to column i: N / 2 columns at
                           //   row pitch ldc -- the gate costs no pass over the [M, 2F] intermediate
+  // ---- LayerNorm folded into the GEMMs around it (round 4; modeling_dinov2.py:361-380: x -> LN -> linear).  With W' = W diag(gamma),
+  // c[n] = sum_k W'[n][k] and b' = b + W beta:   LN(x) W^T + b  =  rstd (x W'^T - mean c) + b'  -- the linear reads the residual row x itself
+  // (in its operand format) and normalises in its epilogue, so no LayerNorm pass reads the fp32 stream.
+  //   producer (the in-place residual epilogue of out-proj / fc2): beside the fp32 row it writes the row in the next GEMM's operand format
+  //   and, per 128-column group g, (sum, centred sum of squares) of the new row to ln_part[m * ln_npart + g] (merged by ln_finalize_kernel);
+  void* ln_op;            //   operand copy of the new residual rows, or null
+  int ln_op_kind;         //   LNOP_BF16 (pitch ln_op_ld bf16) / LNOP_PAIR ([hi | lo], each ln_op_ld / 2 wide) / LNOP_H2 (H2 rows, pitch 2 * ln_op_ld bytes)
+  int ln_op_ld;
+  float2* ln_part;
+  int ln_npart;           //   = ceil(N / 128)
+  //   consumer (QKV, fc1 / weights_in): v = (acc - mean[m] c[n]) rstd[m] before the bias
+  const float2* ln_stats; //   [M] (mean, rstd), or null
+  const float* ln_c;      //   [N]
 };
+enum { LNOP_BF16 = 1, LNOP_PAIR = 2, LNOP_H2 = 3 };
 
 // ----------------------------------------------------------------------------- launchers (all enqueue on `s`, no sync)
 // gemm: C = A[M,K] (row-major, lda) x W[N,K]^T (row-major, ldw)
@@ -191,6 +226,16 @@ int launch_layernorm(const float* x, const float* add, const float* gamma, const
                      int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s,
                      unsigned char* out_fp8 = nullptr, float* out_scale = nullptr, bf16_t* out_split3 = nullptr, int h2 = 0,
                      bf16_t* out_a3 = nullptr);      // out_a3 (with out_f32 only): also the bf16x3 activation layout [hi | hi | lo], row pitch 3*D
+// ---- folded LayerNorm (GemmEpi::ln_*): row statistics only.
+// rows of x -> operand copy of x ITSELF (kind LNOP_*, as GemmEpi::ln_op) + (mean, rstd) per row: what the first block's QKV needs (its
+// producer is the patch embedding, not a residual GEMM)
+int launch_rowstats(const float* x, int rows, int D, float eps, void* op, int op_kind, float2* stats, hipStream_t s);
+// (sum, centred square sum) per 128-column group [rows][npart] -> (mean, rstd) [rows]   (Chan's pairwise combination)
+int launch_ln_finalize(const float2* part, int npart, int rows, int D, float eps, float2* stats, hipStream_t s);
+// pack time: Wout[n][k] = W[n][k] gamma[k],  bias_out[n] = bias_in[n] + sum_k W[n][k] beta[k]   (Wout may alias W, bias_out bias_in)
+int launch_ln_fold(const float* W, int rows, int cols, const float* gamma, const float* beta, const float* bias_in, float* Wout, float* bias_out, hipStream_t s);
+// c[n] = sum_k W[n][k]; round_bf16: of the bf16-rounded elements (what the single-pass bf16 MFMA multiplies)
+int launch_rowsum(const float* W, int rows, int cols, int round_bf16, float* c, hipStream_t s);
 
 // backbone attention, bf16 MFMA flash kernel, head_dim 64.  qkv [B*N, 3*D] bf16 -> ctx [B*N, D] bf16
 int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s);
@@ -248,8 +293,6 @@ int launch_split2(const float* in, int ld_in, bf16_t* out, int rows, int K, hipS
 int launch_split_h2(const float* in, int ld_in, void* out, int rows, int K, unsigned char* wexp, hipStream_t s);
 // H2 GEMM (gemm_pp.hip): A [M, K] activation rows (pitch lda BYTES >= 4K), W [N, K] weight rows (pitch ldw BYTES >= 3K), e.h2_wexp set
 int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
-// fp8 GEMM on the 8-wave ping-pong skeleton (gemm_pp.hip): K % 128 == 0; launch_gemm_fp8 routes the large shapes here
-int launch_gemm_fp8_pp(const unsigned char* A, int lda, const unsigned char* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 // Wave-quantisation tail of the 256x256-tile GEMMs (gemm_pp.hip): when tiles % CUs leaves a short last round (1029 tiles on 256
 // CUs: a fifth round for five tiles, +24 %), the rows of that round are cut off the main launch and computed by a K-SPLIT launch
 // (every tile of the remainder as S slices on S CUs, fp32 partials to a scratch buffer) plus a reduce + epilogue launch.
@@ -263,7 +306,6 @@ int gemm_tail_reserve(size_t bytes);
 int launch_gemm_bf16_k64(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 int gemm_tile_mode();   // tile-order mode word of the 256-row kernels (gemm_x3.hip; gemm_epi.h tile_map)
 // 256x256x64 ping-pong kernel (gemm_pp.hip): K % 64 == 0
-int launch_gemm_bf16_pp(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 int launch_gemm_bf16_ppm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 int launch_gemm_x3(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s);

@@ -133,136 +133,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   drain_tile<BM, BN, 256>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m0 + row_l; });
 }
 
-// ============================================================================================
-// Large-shape variant: 256x256x32 tile, 512 threads = 8 waves (2 along M x 4 along N), each wave a
-// 128x64 sub-tile = 4x2 32x32x16 accumulators (128 acc VGPRs), ONE workgroup per CU.
-// Why 256x256: the per-CU vector-memory -> LDS path tops out near 70 GB/s (MI355X_MICROARCH "Indexed
-// rows": 66-73 GB/s per CU from L2); a 128x128 tile needs 134 GB/s per CU at MFMA peak, 256x256 needs
-// 67 GB/s.  Staging is LDS-DMA into a FOUR-slot ring of 32-KiB K-tiles (BK = 32: 64-B rows, one piece =
-// 16 rows) with up to THREE K-tiles in flight behind counted s_waitcnt vmcnt(N) and ONE raw s_barrier per
-// K-tile (a __syncthreads() would drain the DMA queue):
-//     wait(tile kt landed: vmcnt(8) leaves tiles kt+1, kt+2 in flight) ; barrier ;
-//     issue tile kt+3 into the slot tile kt-1 just vacated ; 16 MFMAs per wave on tile kt
-// Bank swizzle for 64-B rows: 16-B chunk ^= (row>>2)&3 (four rows share a 256-B bank row); applied on
-// the DMA source address and on the ds_read_b128, conflict-free for the b128 lane groups.
-#define B4M 256
-#define B4N 256
+// (The 256x256 8-wave, 256x256x64, 256x128 32x32x16 and 16-wave 256x256x32 variants of rounds 1-2 -- each measured against the kernels
+// below and superseded, DESIGN.md section 4 -- were removed in round 4: git history has them.)
 #define B4K 32
-#define B4_STAGE ((B4M + B4N) * B4K * 2)   // 32 KiB
-#define B4_SLOTS 4
-
-
-__global__ __launch_bounds__(512) void gemm_bf16_256x256_kernel(const bf16_t* __restrict__ A, int lda,
-                                                                const bf16_t* __restrict__ W, int ldw,
-                                                                int M, int N, int K, GemmEpi e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 2, wn = wid & 3;
-  const int tiles_m = (M + B4M - 1) / B4M, tiles_n = (N + B4N - 1) / B4N;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  int tm, tn;
-  {
-    const int GM = 4;     // ~32 resident tiles per XCD: 4 A panels x up to 8 W panels
-    const int per_group = GM * tiles_n;
-    const int grp = bid / per_group, first_m = grp * GM;
-    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-    const int in_g = bid - grp * per_group;
-    tm = first_m + in_g % gsz;
-    tn = in_g / gsz;
-  }
-  const int m0 = tm * B4M, n0 = tn * B4N;
-
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  // per K-tile a wave issues 2 pieces of A and 2 of W; piece = 16 rows x 64 B; lane -> (row = lane>>2, slot = lane&3)
-  const bf16_t* gA0; const bf16_t* gA1; const bf16_t* gW0; const bf16_t* gW1;
-  {
-    auto src = [&](const bf16_t* base, int ld, int r0, int piece, int lim) {
-      const int rl = piece * 16 + (lane >> 2);
-      int r = r0 + rl; r = r < lim ? r : lim - 1;
-      const int c = (lane & 3) ^ ((rl >> 2) & 3);
-      return base + (size_t)r * ld + c * 8;
-    };
-    gA0 = src(A, lda, m0, wid * 2, M); gA1 = src(A, lda, m0, wid * 2 + 1, M);
-    gW0 = src(W, ldw, n0, wid * 2, N); gW1 = src(W, ldw, n0, wid * 2 + 1, N);
-  }
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
-#define STAGE4(slot_, k0)                                                                                  \
-  {                                                                                                        \
-    char* sA_ = smem + (slot_) * B4_STAGE + wu * 2048;                                                     \
-    char* sW_ = sA_ + B4M * B4K * 2;                                                                       \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (k0)), (lptr_t)(sA_), 16, 0, 0);                       \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (k0)), (lptr_t)(sA_ + 1024), 16, 0, 0);                \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sW_), 16, 0, 0);                       \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gW1 + (k0)), (lptr_t)(sW_ + 1024), 16, 0, 0);                \
-  }
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = K / B4K;
-  const int lr = lane & 31, lh = lane >> 5;
-  STAGE4(0, 0)
-  if (nk > 1) STAGE4(1, B4K)
-  if (nk > 2) STAGE4(2, 2 * B4K)
-  // per-lane LDS read offsets (row * 64 + swizzled chunk * 16) for k-step 0; k-step 1 = chunk + 2 -> xor 32 bytes
-  int offA[4], offW[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { const int row = wm * 128 + i * 32 + lr; offA[i] = row * 64 + swz64(row, lh) * 16; }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offW[j] = B4M * B4K * 2 + row * 64 + swz64(row, lh) * 16; }
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int rem = nk - 1 - kt;
-    if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + 3 < nk) STAGE4((kt + 3) & 3, (kt + 3) * B4K)
-    const char* st = smem + (kt & 3) * B4_STAGE;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], wf[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ (kk * 32)));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ (kk * 32)));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-  }
-  // epilogue: two passes of 128 tile rows (64 from each M-half) through a 128 x 256 fp32 LDS tile
-  constexpr int PITCH = B4N * 4 + 16;
-  const ColParams cp = load_col_params<B4N>(e, n0, N, tid);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    __builtin_amdgcn_s_barrier();          // ring (pass 0) / previous pass's tile fully consumed
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        stage_acc(smem, PITCH, wm * 64 + i * 32 + lr, wn * 64 + j * 32, acc[pass * 2 + i][j], lh);
-    __syncthreads();
-    drain_tile<128, B4N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                              [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
-  }
-}
-
 // ============================================================================================
 // Mid variant: 256x128x32 tile, 512 threads = 8 waves (4 along M x 2 along N, 64x64 each), THREE-slot
 // LDS-DMA ring of 24-KiB K-tiles (72 KiB) so that TWO workgroups share a CU: one workgroup's prologue
@@ -274,49 +147,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_256x256_kernel(const bf16_t* __
 #define B5_STAGE ((B5M + B5N) * B4K * 2)   // 24 KiB
 #define B5_SLOTS 3
 
-// ABL (tuning only, tools/bench_gemm_k.py with DINODET_GEMM_ABL): 0 = real kernel; 1 = skip the MFMAs;
-// 2 = skip the LDS fragment reads; 3 = skip the LDS-DMA staging after the prologue.  Outputs are wrong for ABL != 0.
-template <int ABL>
-__global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_kernel(const bf16_t* __restrict__ A, int lda,
-                                                                   const bf16_t* __restrict__ W, int ldw,
-                                                                   int M, int N, int K, GemmEpi e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int tiles_m = (M + B5M - 1) / B5M, tiles_n = (N + B5N - 1) / B5N;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  int tm, tn;
-  {
-    const int GM = 8;     // ~64 resident tiles per XCD: 8 A panels x 8 W panels
-    const int per_group = GM * tiles_n;
-    const int grp = bid / per_group, first_m = grp * GM;
-    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-    const int in_g = bid - grp * per_group;
-    tm = first_m + in_g % gsz;
-    tn = in_g / gsz;
-  }
-  const int m0 = tm * B5M, n0 = tn * B5N;
-
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  // per K-tile a wave issues 2 pieces of A and 1 of W; piece = 16 rows x 64 B
-  const bf16_t* gA0; const bf16_t* gA1; const bf16_t* gW0;
-  {
-    auto src = [&](const bf16_t* base, int ld, int r0, int piece, int lim) {
-      const int rl = piece * 16 + (lane >> 2);
-      int r = r0 + rl; r = r < lim ? r : lim - 1;
-      const int c = (lane & 3) ^ ((rl >> 2) & 3);
-      return base + (size_t)r * ld + c * 8;
-    };
-    gA0 = src(A, lda, m0, wid * 2, M); gA1 = src(A, lda, m0, wid * 2 + 1, M);
-    gW0 = src(W, ldw, n0, wid, N);
-  }
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
 #define STAGE5(slot_, k0)                                                                                  \
   {                                                                                                        \
     char* sA_ = smem + (slot_) * B5_STAGE + wu * 2048;                                                     \
@@ -326,188 +156,6 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_kernel(const bf16_t*
     __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sW_), 16, 0, 0);                       \
   }
 
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = K / B4K;
-  const int lr = lane & 31, lh = lane >> 5;
-  STAGE5(0, 0)
-  if (nk > 1) STAGE5(1, B4K)
-  int offA[2], offW[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { const int row = wm * 64 + i * 32 + lr; offA[i] = row * 64 + swz64(row, lh) * 16; }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offW[j] = B5M * B4K * 2 + row * 64 + swz64(row, lh) * 16; }
-
-  int slot = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + 2 < nk && ABL != 3) {
-      const int ns = slot >= 1 ? slot - 1 : 2;      // (slot + 2) % 3
-      STAGE5(ns, (kt + 2) * B4K)
-    }
-    const char* st = smem + slot * B5_STAGE;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[2], wf[2];
-      if (ABL == 2) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { af[i] = __builtin_bit_cast(bf16x8, make_uint4(kt, lane, i, kk)); wf[i] = af[i]; asm volatile("" : "+v"(af[i]), "+v"(wf[i])); }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ (kk * 32)));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ (kk * 32)));
-      }
-      if (ABL == 1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(af[i]), "v"(wf[i]));
-      } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-      }
-    }
-    slot = slot == 2 ? 0 : slot + 1;
-  }
-  // epilogue: two passes of 128 tile rows (32 from each wave row) through a 128 x 128 fp32 LDS tile
-  constexpr int PITCH = B5N * 4 + 16;
-  const ColParams cp = load_col_params<B5N>(e, n0, N, tid);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      stage_acc(smem, PITCH, wm * 32 + lr, wn * 64 + j * 32, acc[pass][j], lh);
-    __syncthreads();
-    drain_tile<128, B5N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                              [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
-  }
-}
-
-// ============================================================================================
-// 256x256x64 variant: 128-byte LDS rows (one LDS-DMA piece = 8 rows x 128 B = eight FULL cache lines; the
-// 64-byte rows of the BK=32 kernels make every line two half-line requests -- measured: the staging stream
-// alone runs at ~50 GB/s per CU with 64-B rows, and that stream, not the MFMAs, bounds those kernels).
-// Two 64-KiB stages, one workgroup per CU; tile kt+1 streams in while tile kt (32 MFMAs per wave) computes.
-#define B7_STAGE ((B4M + B4N) * BK * 2)   // 64 KiB
-
-__global__ __launch_bounds__(512) void gemm_bf16_256x256x64_kernel(const bf16_t* __restrict__ A, int lda,
-                                                                   const bf16_t* __restrict__ W, int ldw,
-                                                                   int M, int N, int K, GemmEpi e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 2, wn = wid & 3;
-  const int tiles_m = (M + B4M - 1) / B4M, tiles_n = (N + B4N - 1) / B4N;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  int tm, tn;
-  {
-    const int GM = 4;
-    const int per_group = GM * tiles_n;
-    const int grp = bid / per_group, first_m = grp * GM;
-    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-    const int in_g = bid - grp * per_group;
-    tm = first_m + in_g % gsz;
-    tn = in_g / gsz;
-  }
-  const int m0 = tm * B4M, n0 = tn * B4N;
-
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  // per K-tile a wave issues 4 pieces of A and 4 of W; piece = 8 rows x 128 B
-  const bf16_t* gA[4];
-  const bf16_t* gW[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rl = (wid * 4 + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((rl >> 1) & 7);
-    int ra = m0 + rl; ra = ra < M ? ra : M - 1;
-    int rw = n0 + rl; rw = rw < N ? rw : N - 1;
-    gA[i] = A + (size_t)ra * lda + c * 8;
-    gW[i] = W + (size_t)rw * ldw + c * 8;
-  }
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
-#define STAGE7(stage_, k0)                                                                                  \
-  {                                                                                                        \
-    char* sA_ = smem + (stage_) * B7_STAGE + wu * 4096;                                                     \
-    char* sW_ = sA_ + B4M * BK * 2;                                                                         \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                      \
-      __builtin_amdgcn_global_load_lds((gptr_t)(gA[i_] + (k0)), (lptr_t)(sA_ + i_ * 1024), 16, 0, 0);       \
-      __builtin_amdgcn_global_load_lds((gptr_t)(gW[i_] + (k0)), (lptr_t)(sW_ + i_ * 1024), 16, 0, 0);       \
-    }                                                                                                      \
-  }
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = K / BK;
-  const int lr = lane & 31, lh = lane >> 5;
-  STAGE7(0, 0)
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + 1 < nk) STAGE7((kt + 1) & 1, (kt + 1) * BK)
-    const char* sA = smem + (kt & 1) * B7_STAGE;
-    const char* sW = sA + B4M * BK * 2;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 af[4], wf[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wm * 128 + i * 32 + lr;
-        af[i] = *reinterpret_cast<const bf16x8*>(sA + row * 128 + swz128(row, kk * 2 + lh) * 16);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = wn * 64 + j * 32 + lr;
-        wf[j] = *reinterpret_cast<const bf16x8*>(sW + row * 128 + swz128(row, kk * 2 + lh) * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-  }
-  constexpr int PITCH = B4N * 4 + 16;
-  const ColParams cp = load_col_params<B4N>(e, n0, N, tid);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        stage_acc(smem, PITCH, wm * 64 + i * 32 + lr, wn * 64 + j * 32, acc[pass * 2 + i][j], lh);
-    __syncthreads();
-    drain_tile<128, B4N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                              [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
-  }
-}
-
 // ============================================================================================
 // 256x128x32 with v_mfma_f32_16x16x32_bf16 (4x4 accumulators of 16x16 per wave) -- same tile, ring and epilogue as
 // the 32x32x16 kernel; the chip can hold a higher clock on this shape (cdna guide 5.4 rule 28: build both, keep the
@@ -515,9 +163,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_256x256x64_kernel(const bf16_t*
 // swizzle becomes chunk ^= ((row>>3)&1)<<1 (conflict-free for the ds_read_b128 lane groups with that lane map).
 __device__ __forceinline__ int swz64m16(int row, int chunk) { return chunk ^ (((row >> 3) & 1) << 1); }
 
-// tuning only (tools/gemm_timeline.py): when non-null, thread 0 of every workgroup stores
+#ifdef DINODET_TUNING
+// tuning builds only (tools/gemm_timeline.py): when non-null, thread 0 of every workgroup stores
 // {s_memrealtime at start, after the K loop, at exit (stores drained), blockIdx}
 __device__ unsigned long long* g_gemm_stamps = nullptr;
+#endif
 
 __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf16_t* __restrict__ A, int lda,
                                                                        const bf16_t* __restrict__ W, int ldw,
@@ -527,9 +177,11 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_m = (M + B5M - 1) / B5M, tiles_n = (N + B5N - 1) / B5N;
   const int nwg = tiles_m * tiles_n;
+#ifdef DINODET_TUNING
   unsigned long long* stamps = g_gemm_stamps;
   unsigned long long t_start = 0, t_loop = 0;
   if (stamps) t_start = __builtin_amdgcn_s_memrealtime();
+#endif
   int tm, tn;
   tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
   const int m0 = tm * B5M, n0 = tn * B5N;
@@ -584,7 +236,9 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     slot = slot == 2 ? 0 : slot + 1;
   }
+#ifdef DINODET_TUNING
   if (stamps) t_loop = __builtin_amdgcn_s_memrealtime();
+#endif
   // epilogue: D = W A^T: lane&15 = m within the 16-row block, (lane>>4)*4 + reg = n within the 16-col block
   constexpr int PITCH = B5N * 4 + 16;
   const ColParams cp = load_col_params<B5N>(e, n0, N, tid);
@@ -605,141 +259,18 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
     drain_tile<128, B5N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
                               [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
   }
+#ifdef DINODET_TUNING
   if (stamps && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned long long* o = stamps + (size_t)blockIdx.x * 4;
     o[0] = t_start; o[1] = t_loop; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = blockIdx.x;
   }
-}
-
-// ============================================================================================
-// 256x256x32 with SIXTEEN waves (1024 threads, 4x4 waves of 64x64, 16x16x32 MFMA): one workgroup per CU but four
-// waves per SIMD, so barrier / LDS-latency stalls of one wave are covered by three others (the 8-wave 256x256 kernels
-// above cannot).  Measured motivation (tools/gemm_timeline.py, ablations): the 256x128 kernel runs at 92 % of what the
-// per-CU vector-memory pipe (~48 GB/s) allows for ITS bytes (576 KiB staged + 64 KiB stored per tile at K = 768);
-// a 256x256 tile moves 29 % fewer bytes per FLOP through that pipe.
-// Four-slot ring of 32-KiB K-tiles, three in flight: vmcnt(4) (2 pieces per wave per K-tile), one barrier per K-tile.
-#define B9_STAGE ((B4M + B4N) * B4K * 2)   // 32 KiB
-#define B9_SLOTS 4
-
-template <int ABL>
-__global__ __launch_bounds__(1024) void gemm_bf16_256x256_w16_kernel(const bf16_t* __restrict__ A, int lda,
-                                                                     const bf16_t* __restrict__ W, int ldw,
-                                                                     int M, int N, int K, GemmEpi e, int GM) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 2, wn = wid & 3;
-  const int tiles_m = (M + B4M - 1) / B4M, tiles_n = (N + B4N - 1) / B4N;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  int tm, tn;
-  {
-    const int per_group = GM * tiles_n;
-    const int grp = bid / per_group, first_m = grp * GM;
-    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-    const int in_g = bid - grp * per_group;
-    tm = first_m + in_g % gsz;
-    tn = in_g / gsz;
-  }
-  const int m0 = tm * B4M, n0 = tn * B4N;
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  // per K-tile a wave issues ONE piece of A and ONE of W (piece = 16 rows x 64 B; 16 pieces per operand)
-  const bf16_t* gA0; const bf16_t* gW0;
-  {
-    auto src = [&](const bf16_t* base, int ld, int r0, int piece, int lim) {
-      const int rl = piece * 16 + (lane >> 2);
-      int r = r0 + rl; r = r < lim ? r : lim - 1;
-      const int c = swz64m16(rl, lane & 3);
-      return base + (size_t)r * ld + c * 8;
-    };
-    gA0 = src(A, lda, m0, wid, M);
-    gW0 = src(W, ldw, n0, wid, N);
-  }
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
-#define STAGE9(slot_, k0)                                                                                  \
-  {                                                                                                        \
-    char* sA_ = smem + (slot_) * B9_STAGE + wu * 1024;                                                     \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (k0)), (lptr_t)(sA_), 16, 0, 0);                       \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sA_ + B4M * B4K * 2), 16, 0, 0);       \
-  }
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nk = K / B4K;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  STAGE9(0, 0)
-  if (nk > 1) STAGE9(1, B4K)
-  if (nk > 2) STAGE9(2, 2 * B4K)
-  int offA[4], offW[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { const int row = wm * 64 + i * 16 + l15; offA[i] = row * 64 + swz64m16(row, l4) * 16; }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { const int row = wn * 64 + j * 16 + l15; offW[j] = B4M * B4K * 2 + row * 64 + swz64m16(row, l4) * 16; }
-  for (int kt = 0; kt < nk; ++kt) {
-    const int rem = nk - 1 - kt;
-    if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + 3 < nk && ABL != 3) STAGE9((kt + 3) & 3, (kt + 3) * B4K)
-    const char* st = smem + (kt & 3) * B9_STAGE;
-    bf16x8 af[4], wf[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + offA[i]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + offW[j]);
-    if (ABL == 1) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(af[i]), "v"(wf[i]));
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-  }
-  // epilogue: two passes of 128 tile rows through a 128 x 256 fp32 LDS tile (pitch +16 B)
-  constexpr int PITCH = B4N * 4 + 16;
-  const ColParams cp = load_col_params<B4N>(e, n0, N, tid);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row_l = wm * 32 + ii * 16 + l15;
-        const int col = wn * 64 + j * 16 + 4 * l4;
-        const f32x4 a = acc[pass * 2 + ii][j];
-        *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
-      }
-    __syncthreads();
-    drain_tile<128, B4N, 1024>(smem, PITCH, e, cp, M, N, n0, tid,
-                               [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
-  }
+#endif
 }
 
 // dynamic LDS: the staging ring, or the padded fp32 epilogue tile if larger
 static constexpr int LDS128 = (BM * (BN * 4 + 16)) > 2 * STAGE_BYTES ? (BM * (BN * 4 + 16)) : 2 * STAGE_BYTES;
 static constexpr int LDS5 = (128 * (B5N * 4 + 16)) > B5_SLOTS * B5_STAGE ? (128 * (B5N * 4 + 16)) : B5_SLOTS * B5_STAGE;
-static constexpr int LDS7 = (128 * (B4N * 4 + 16)) > 2 * B7_STAGE ? (128 * (B4N * 4 + 16)) : 2 * B7_STAGE;
-static constexpr int LDS9 = (128 * (B4N * 4 + 16)) > B9_SLOTS * B9_STAGE ? (128 * (B4N * 4 + 16)) : B9_SLOTS * B9_STAGE;
-static constexpr int LDS256 = (128 * (B4N * 4 + 16)) > B4_SLOTS * B4_STAGE ? (128 * (B4N * 4 + 16)) : B4_SLOTS * B4_STAGE;
-
-extern "C" int dod_debug_gemm_stamps(void* dev_buf) {
-  unsigned long long* p = (unsigned long long*)dev_buf;
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 4;
-}
 
 int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K,
                      const GemmEpi& e, hipStream_t s) {
@@ -747,113 +278,65 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   if (K % BK != 0 || N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256x64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS7);
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_m16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256_w16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS9);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256_w16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS9);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x256_w16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS9);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
-    attr_set = true;
+    attr_set[dev] = true;
   }
-  const char* force = getenv("DINODET_GEMM_TILE");     // "128" / "256": tuning override
+  const char* force = DOD_TUNE_ENV("DINODET_GEMM_TILE");     // tuning builds: "q" ping-pong, "x" 16-wave k64, "8" 256x128, "1" 128x128
   if (!force && M >= 2048 && N >= 512 && e.act != ACT_GELU && e.act != ACT_SIGMOID && e.rows_per_img == 0 && K % 64 == 0) {   // the 256x256-tile shapes
     const int t = gemm_tail_split(0, A, lda, W, ldw, M, N, K, e, s);      // short last round (M >= 8192), or a grid of a few dozen tiles (M >= 2048)
     if (t >= 0) return t;
   }
-  // 256x256x64, 16 waves, two 64-KiB slots (the structure of gemm_x3.hip with k 32..63 in the second planes): measured at
-  // M = 87680 against the kernels below -- QKV 760 vs 700, out-proj 460 vs 423, fc2 765 vs 709 TFLOP/s; fc1 650 vs 652: with
-  // one workgroup per CU nothing hides the GELU epilogue, so activations with a transcendental stay on the 2-workgroup kernel.
-  // (also at small grids: at M = 10960 -- batch 8 -- QKV 730 vs 639, out-proj 396 vs 375, fc2 634 vs 526 TFLOP/s)
-  if (force && force[0] == 'p' && K % 64 == 0) return launch_gemm_bf16_pp(A, lda, W, ldw, M, N, K, e, s);
-  if (force && (force[0] == 'q' || force[0] == 'r') && K % 64 == 0) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
+  if (force && force[0] == 'q' && K % 64 == 0) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
   if (force && force[0] == 'x') return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
-  static const char* rule_env = getenv("DINODET_GEMM_RULE");     // "0": the round-1 heuristic below (A/B)
-  if (rule_env && rule_env[0] == '0') {
-    if (!force && M >= 4096 && N >= 512 && e.act != ACT_GELU && e.act != ACT_SIGMOID && e.rows_per_img == 0) return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
-  } else
+  // grouped-order depth of the 256x128 kernel (m-tiles per group inside an XCD's run), measured: 8 for N = 3072, 4 for 2304, 2 for 768
+  const int gm5 = (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2)) | (gemm_tile_mode() & 0x300);
+  const int tiles5 = ((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
   if (!force && M >= 4096 && N >= 512 && K % 64 == 0 && e.act != ACT_SIGMOID && e.rows_per_img == 0) {
-    // Round-aware choice between the 256x256 tiles (one workgroup per CU: `k64`, or the 8-wave ping-pong kernel, which is 3-7 % faster
-    // on N >= 1536 at every M measured) and the 256x128 tile (`m16`, two co-resident workgroups per CU that run at about half speed
-    // each, so one of its tiles costs ~0.55 of a 256x256 tile only while a CU holds a single one).  Cost in units of a 256x256 tile
-    // time = rounds of CUs x tile cost; a GELU epilogue costs the one-workgroup-per-CU kernels ~8 % (nothing overlaps it).
-    // tools/bench_pp.py --rows {4112, 8224, 16448, 21920, 43840, 87680}: the rule reproduces the faster kernel in 23 of 24 cases
+    // Round-aware choice between the 256x256 tiles (one workgroup per CU: the 16-wave `k64` kernel of gemm_x3.hip -- 256x256x64, two 64-KiB
+    // slots: QKV 760 / out-proj 460 / fc2 765 TFLOP/s at M = 87 680 -- or the 8-wave ping-pong kernel of gemm_pp.hip, 3-7 % faster on
+    // N >= 1536 at every M measured) and the 256x128 tile (`m16`, two co-resident workgroups per CU that run at about half speed each, so
+    // one of its tiles costs ~0.55 of a 256x256 tile only while a CU holds a single one).  Cost in units of a 256x256 tile time = rounds
+    // of CUs x tile cost; a GELU epilogue costs the one-workgroup-per-CU kernels ~8 % (nothing overlaps it).
+    // tools/bench_pp.py --rows {4112, 8224, 16448, 21920, 43840, 87680}: the rule reproduces the faster kernel in 27 of 28 cases
     // (M = 8224, batch 32 at 224x224: QKV 46 vs 53 us, out-proj 27 vs 32, fc1 66 vs 78, fc2 59 vs 75).
-    static int cus = 0;
-    if (!cus) { int dev = 0, c = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); cus = c > 0 ? c : 256; }
+    static int cus[16] = {};
+    if (dev >= 0 && dev < 16 && !cus[dev]) { int c = 0; (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); cus[dev] = c > 0 ? c : 256; }
+    const int cu = (dev >= 0 && dev < 16) ? cus[dev] : 256;
     const long tm = (M + 255) / 256, t_big = tm * ((N + 255) / 256), t_small = tm * ((N + 127) / 128);
-    const double c_big = (double)((t_big + cus - 1) / cus) * (e.act == ACT_GELU ? 1.08 : 1.0);
-    const double c_small = (double)((t_small + cus - 1) / cus) * (K >= 2048 ? 0.62 : 0.55);      // long K: the smaller tile's lower FLOP per staged byte shows
+    const double c_big = (double)((t_big + cu - 1) / cu) * (e.act == ACT_GELU ? 1.08 : 1.0);
+    const double c_small = (double)((t_small + cu - 1) / cu) * (K >= 2048 ? 0.62 : 0.55);      // long K: the smaller tile's lower FLOP per staged byte shows
     if (c_big <= c_small * 1.02) {
       if (N >= 1536) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
       return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
     }
-    {
-      static const char* gme = getenv("DINODET_GEMM_GM");
-      const int gm = (gme ? (atoi(gme) & 0xff) : (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2))) | (gemm_tile_mode() & 0x300);
-      const int tiles = ((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
-      hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e, gm);
-      return hipGetLastError() == hipSuccess ? 0 : 3;
-    }
+    hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel, dim3(tiles5), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e, gm5);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
   }
-  // shape heuristic (measured on MI355X, tools/bench_gemm_k.py / bench_ops.py at M = 87680, random data):
-  //   256x128x32 with v_mfma_f32_16x16x32_bf16, two workgroups per CU: QKV 703, out-proj 437, fc1 646, fc2 643 TFLOP/s
-  //   same tile with 32x32x16: 651 / 405 / 607 / 621;  256x256 (one per CU): 624 / 342 / 554 / 619-643
-  // -> the 16x16x32 kernel for every large-M shape; 128x128 for small M (decoder memory at small batch, tests).
-  // a grid of a few dozen 256x128 tiles (the decoder's query-side linears: B*Q = 3 200 rows at batch 32 -> 78 workgroups walking K' = 3K
-  // = 2 304) leaves most CUs idle, and one workgroup per CU pulls its operands at the per-CU staging rate whatever its tile: the 128x128
-  // kernel puts the same bytes on twice as many CUs.  tools/bench_small_m.py, M = 3200: N = 768 41.5 -> 30.9 us, N = 1024 42.7 -> 31.9,
-  // K = 3072 53.9 -> 38.7; N = 2304 (234 tiles) 47.8 vs 48.4: stays.  DINODET_GEMM_SMALLGRID=0 restores the round-2 choice (A/B).
-  static const bool smallgrid = [] { const char* v = getenv("DINODET_GEMM_SMALLGRID"); return !(v && v[0] == '0'); }();
-  const long tiles5 = (long)((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
-  const bool few = smallgrid && tiles5 * 2 <= 256 + 64;
+  // Below that: 256x128x32 on v_mfma_f32_16x16x32_bf16 (two workgroups per CU) from 1 024 rows up, 128x128 for small M (decoder memory at small
+  // batch, tests) -- and for a grid of a few dozen 256x128 tiles (the decoder's query-side linears: B*Q = 3 200 rows at batch 32 -> 78 workgroups
+  // walking K' = 3K = 2 304), which leaves most CUs idle while one workgroup per CU pulls its operands at the per-CU staging rate whatever its
+  // tile: the 128x128 kernel puts the same bytes on twice as many CUs (tools/bench_small_m.py, M = 3200: N = 768 41.5 -> 30.9 us, N = 1024
+  // 42.7 -> 31.9, K = 3072 53.9 -> 38.7; N = 2304 (234 tiles) 47.8 vs 48.4: stays).
+  const bool few = (long)tiles5 * 2 <= 256 + 64;
   const bool m16 = force ? (force[0] == '8') : (M >= 1024 && N >= 128 && !few);
-  const bool mid = force ? (force[0] == '5') : false;
-  const bool big = force ? (force[0] == '2') : false;
-  // 16-wave 256x256 for long K (fc2: 581 vs 622 us at M = 87680): its 130 us fixed cost only pays off there
-  const bool w16 = force ? (force[0] == '9') : (M >= 4096 && N >= 512 && K >= 2048);
-  if (w16) {
-    static const char* gme9 = getenv("DINODET_GEMM_GM");
-    const int gm = gme9 ? atoi(gme9) : 4;
-    const int tiles = ((M + B4M - 1) / B4M) * ((N + B4N - 1) / B4N);
-    static const char* ab9 = getenv("DINODET_GEMM_ABL");
-    const int abl9 = ab9 ? atoi(ab9) : 0;
-    if (abl9 == 1) hipLaunchKernelGGL(gemm_bf16_256x256_w16_kernel<1>, dim3(tiles), dim3(1024), LDS9, s, A, lda, W, ldw, M, N, K, e, gm);
-    else if (abl9 == 3) hipLaunchKernelGGL(gemm_bf16_256x256_w16_kernel<3>, dim3(tiles), dim3(1024), LDS9, s, A, lda, W, ldw, M, N, K, e, gm);
-    else hipLaunchKernelGGL(gemm_bf16_256x256_w16_kernel<0>, dim3(tiles), dim3(1024), LDS9, s, A, lda, W, ldw, M, N, K, e, gm);
-  } else if (m16) {
-    // grouped-order depth (m-tiles per group inside an XCD's run), measured: 8 for N = 3072, 4 for 2304, 2 for 768
-    static const char* gme = getenv("DINODET_GEMM_GM");
-    const int gm = (gme ? (atoi(gme) & 0xff) : (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2))) | (gemm_tile_mode() & 0x300);
-    const int tiles = ((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
-    hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e, gm);
-  } else if (force && force[0] == '7') {
-    const int tiles = ((M + B4M - 1) / B4M) * ((N + B4N - 1) / B4N);
-    hipLaunchKernelGGL(gemm_bf16_256x256x64_kernel, dim3(tiles), dim3(512), LDS7, s, A, lda, W, ldw, M, N, K, e);
-  } else if (mid) {
-    const int tiles = ((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
-    const char* ab = getenv("DINODET_GEMM_ABL");
-    const int abl = ab ? atoi(ab) : 0;
-    if (abl == 1) hipLaunchKernelGGL(gemm_bf16_256x128_kernel<1>, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
-    else if (abl == 2) hipLaunchKernelGGL(gemm_bf16_256x128_kernel<2>, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
-    else if (abl == 3) hipLaunchKernelGGL(gemm_bf16_256x128_kernel<3>, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
-    else hipLaunchKernelGGL(gemm_bf16_256x128_kernel<0>, dim3(tiles), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e);
-  } else if (big) {
-    const int tiles = ((M + B4M - 1) / B4M) * ((N + B4N - 1) / B4N);
-    hipLaunchKernelGGL(gemm_bf16_256x256_kernel, dim3(tiles), dim3(512), LDS256, s, A, lda, W, ldw, M, N, K, e);
+  if (m16) {
+    hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel, dim3(tiles5), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e, gm5);
   } else {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles), dim3(256), LDS128, s, A, lda, W, ldw, M, N, K, e);
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+#ifdef DINODET_TUNING
+extern "C" int dod_debug_gemm_stamps(void* dev_buf) {
+  unsigned long long* p = (unsigned long long*)dev_buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 4;
 }
 
 // ---- tuning only (tools/mfma_peak.py): register-only MFMA loop, no memory traffic -----------------------------
@@ -988,4 +471,4 @@ extern "C" int dod_debug_mfma_valu_probe(int nvalu, int mode, int iters, int blo
   if (nvalu == 56) return probe_launch<56>(mode, iters, blocks, dev_out, stream);
   return 1;
 }
-
+#endif  // DINODET_TUNING

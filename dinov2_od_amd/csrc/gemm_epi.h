@@ -12,9 +12,10 @@ __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row 
 // Chunked map: the tile list is cut into chunks of 8 groups; group k of a chunk runs on XCD k, chunks run one after the other, so
 // the whole chip moves through M together -- in the order the producer kernel wrote the A rows (or, with the reverse bit, most
 // recently written rows first: those are the ones still in the 256-MiB Infinity Cache).  Both maps are bijections for any grid.
-// Start stagger (mode bits 16..27 = delay step in units of 0.16 us, bits 12..15 = groups - 1): the workgroups of the first round
+// (tuning builds) Start stagger (mode bits 16..27 = delay step in units of 0.16 us, bits 12..15 = groups - 1): the workgroups of the first round
 // (one per CU) in group k = (b / 8) % groups start k steps late, so that the CUs' HBM-bound epilogues -- which otherwise all run at
 // the same instants, between compute-only K loops -- interleave with the other groups' K loops.
+#ifdef DINODET_TUNING
 __device__ __forceinline__ void stagger_start(int b, int mode) {
   const int sd = (mode >> 16) & 0xfff;
   if (sd == 0 || b >= 256) return;
@@ -24,11 +25,16 @@ __device__ __forceinline__ void stagger_start(int b, int mode) {
   while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
 }
 
+#endif
+
 __device__ __forceinline__ void tile_map(int b, int tiles_m, int tiles_n, int mode, int* tm_out, int* tn_out) {
+#ifdef DINODET_TUNING
   stagger_start(b, mode);
+#endif
   const int GM = mode & 0xff;
   const int nwg = tiles_m * tiles_n;
   int tm, tn;
+#ifdef DINODET_TUNING
   if (mode & 0x400) {
     // weight-resident map (tiles_n even; grid = 8 * ceil(tiles_m / 4) * tiles_n / 2, padded: tm = -1 -> the workgroup exits): XCD x owns
     // n-half x & 1 -- half the weight matrix stays in its L2 -- and every fourth m-tile; it walks n fastest, so the tiles that share an
@@ -37,7 +43,9 @@ __device__ __forceinline__ void tile_map(int b, int tiles_m, int tiles_n, int mo
     tm = (idx / hn) * 4 + (xcd >> 1);
     tn = (xcd & 1) * hn + idx % hn;
     if (tm >= tiles_m) tm = -1;
-  } else if (mode & 0x200) {
+  } else
+#endif
+  if (mode & 0x200) {
     const int per_group = GM * tiles_n;
     const int nfull = tiles_m / (8 * GM);                  // full chunks
     const int body = nfull * 8 * per_group;
@@ -95,14 +103,51 @@ __device__ __forceinline__ ColParams load_col_params(const GemmEpi& e, int n0, i
   const int n = n0 + 4 * (tid % (COLS / 4));
   const bool ok = n < N;
   c.bias = (e.bias && ok) ? *reinterpret_cast<const float4*>(e.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-  c.scale = (e.scale && ok) ? *reinterpret_cast<const float4*>(e.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float* sc = e.ln_stats ? e.ln_c : e.scale;      // folded LayerNorm (never together with a LayerScale): the column sums c[n]
+  c.scale = (sc && ok) ? *reinterpret_cast<const float4*>(sc + n) : make_float4(1.f, 1.f, 1.f, 1.f);
   c.wscale = (e.w_scale && ok) ? *reinterpret_cast<const float4*>(e.w_scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
   return c;
 }
 
-template <int RB, int STEP, int ITER, int C4, typename RowMap>
-__device__ __forceinline__ void drain_resid(const char* sm, int pitch, const GemmEpi& e, const ColParams& cp, int M, int n, int c4, int tid, RowMap rowmap) {
+// sum over the 32 lanes (= 128 output columns) a lane's row group consists of / starts with
+__device__ __forceinline__ float group32_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// the new residual row in the operand format of the GEMM that reads it next (GemmEpi::ln_op; the writers of rowops.hip's LayerNorm)
+__device__ __forceinline__ void ln_store_op(const GemmEpi& e, size_t m, int n, int N, const float4& v) {
+  if (e.ln_op_kind == LNOP_H2) {
+    uint2 f16; unsigned hi8, lo8;
+    h2_quad(v, 1.0f, f16, hi8, lo8);
+    char* row = reinterpret_cast<char*>(e.ln_op) + m * (size_t)e.ln_op_ld * 2;
+    *reinterpret_cast<uint2*>(row + 2 * n) = f16;
+    char* p8 = row + h2_off8(N, n);
+    *reinterpret_cast<unsigned*>(p8) = hi8;
+    *reinterpret_cast<unsigned*>(p8 + 16) = lo8;
+    return;
+  }
+  uint2 hi;
+  hi.x = pack2bf(v.x, v.y);
+  hi.y = pack2bf(v.z, v.w);
+  bf16_t* o = reinterpret_cast<bf16_t*>(e.ln_op) + m * (size_t)e.ln_op_ld + n;
+  *reinterpret_cast<uint2*>(o) = hi;
+  if (e.ln_op_kind == LNOP_PAIR) {
+    uint2 lo;
+    lo.x = pack2bf(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = pack2bf(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
+    *reinterpret_cast<uint2*>(o + (e.ln_op_ld >> 1)) = lo;
+  }
+}
+
+// LNF: the folded-LayerNorm producer (GemmEpi::ln_part): every lane stays in the loop (columns n >= N contribute nothing) because the row
+// statistics are reduced across the 32 lanes of a 128-column group
+template <int RB, int STEP, int ITER, int C4, bool LNF, typename RowMap>
+__device__ __forceinline__ void drain_resid(const char* sm, int pitch, const GemmEpi& e, const ColParams& cp, int M, int N, int n, int c4, int tid, RowMap rowmap) {
   const int rb = tid / C4;
+  const bool nv = !LNF || n < N;
+  const int g0 = n & ~127;                                       // first column of the lane's statistics group
+  const float inv_cnt = LNF ? 1.0f / (float)((N - g0) < 128 ? ((N - g0) > 0 ? (N - g0) : 1) : 128) : 0.f;
 #pragma unroll 1
   for (int it = 0; it < ITER; it += RB) {
     float4 r[RB];
@@ -111,18 +156,28 @@ __device__ __forceinline__ void drain_resid(const char* sm, int pitch, const Gem
     for (int j = 0; j < RB; ++j) {
       mm[j] = rowmap(rb + (it + j) * STEP);
       r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mm[j] < M) r[j] = *reinterpret_cast<const float4*>(e.resid + (size_t)mm[j] * e.ldr + n);
+      if (mm[j] < M && nv) r[j] = *reinterpret_cast<const float4*>(e.resid + (size_t)mm[j] * e.ldr + n);
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-      if (mm[j] >= M) continue;
+      if (!LNF && mm[j] >= M) continue;
+      const bool ok = nv && mm[j] < M;      // (LNF: predicated instead of skipped -- the group reductions below are wave-level operations)
       float4 v = *reinterpret_cast<const float4*>(sm + (rb + (it + j) * STEP) * pitch + c4 * 16);
       v.x += cp.bias.x; v.y += cp.bias.y; v.z += cp.bias.z; v.w += cp.bias.w;
       if (e.act == ACT_GELU) { gelu_fast4(v); }
       else if (e.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       v.x = fmaf(v.x, cp.scale.x, r[j].x); v.y = fmaf(v.y, cp.scale.y, r[j].y);
       v.z = fmaf(v.z, cp.scale.z, r[j].z); v.w = fmaf(v.w, cp.scale.w, r[j].w);
-      *reinterpret_cast<float4*>(e.out_f32 + (size_t)mm[j] * e.ldc + n) = v;
+      if (ok) *reinterpret_cast<float4*>(e.out_f32 + (size_t)mm[j] * e.ldc + n) = v;
+      if (LNF) {
+        if (ok && e.ln_op) ln_store_op(e, (size_t)mm[j], n, N, v);
+        // (sum, centred square sum) of the row's 128-column group: two-pass inside the group, merged exactly by ln_finalize_kernel
+        const float sum = group32_sum(nv ? (v.x + v.y) + (v.z + v.w) : 0.f);
+        const float mg = sum * inv_cnt;
+        const float a = v.x - mg, b = v.y - mg, c = v.z - mg, d = v.w - mg;
+        const float sq = group32_sum(nv ? (a * a + b * b) + (c * c + d * d) : 0.f);
+        if ((c4 & 31) == 0 && ok) e.ln_part[(size_t)mm[j] * e.ln_npart + (n >> 7)] = make_float2(sum, sq);
+      }
     }
   }
 }
@@ -133,9 +188,10 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
                                            int n0, int tid, RowMap rowmap) {
   constexpr int C4 = COLS / 4;
   static_assert(NT % C4 == 0, "a thread must keep its column group");
+  static_assert(C4 % 32 == 0, "a 128-column statistics group is 32 lanes of one wave");
   const int c4 = tid % C4;
   const int n = n0 + 4 * c4;
-  if (n >= N) return;
+  if (n >= N && !e.ln_part) return;
   if (e.resid && e.out_f32 && e.rows_per_img == 0 && !e.a_scale && !e.a_bs) {
     // The in-place fp32 residual epilogue (out-proj, fc2): a thread visits ROWS / (NT / C4) rows, and with one residual load in flight
     // per thread the pass is a chain of memory latencies (tools/pp_timeline.py: 63 k cycles per 256x256 tile, 15 GB/s per CU).
@@ -144,10 +200,12 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
     // (128 VGPRs: out-proj 235 vs 204 us); the 512-thread kernels (256 VGPRs) take a deeper batch through e.rb (round 3).
     constexpr int STEP = NT / C4, ITER = ROWS / STEP;
     static_assert(ROWS % STEP == 0, "whole passes over the tile rows");
-    if (NT <= 512 && ITER % 8 == 0 && e.rb == 8) { drain_resid<8, STEP, ITER, C4>(sm, pitch, e, cp, M, n, c4, tid, rowmap); return; }
-    drain_resid<(ITER % 4 == 0 ? 4 : (ITER % 2 == 0 ? 2 : 1)), STEP, ITER, C4>(sm, pitch, e, cp, M, n, c4, tid, rowmap);
+    constexpr int RBD = ITER % 4 == 0 ? 4 : (ITER % 2 == 0 ? 2 : 1);
+    if (e.ln_part) { drain_resid<RBD, STEP, ITER, C4, true>(sm, pitch, e, cp, M, N, n, c4, tid, rowmap); return; }
+    drain_resid<RBD, STEP, ITER, C4, false>(sm, pitch, e, cp, M, N, n, c4, tid, rowmap);
     return;
   }
+  if (n >= N) return;
 #pragma unroll
   for (int row_l = tid / C4; row_l < ROWS; row_l += NT / C4) {
     const int m = rowmap(row_l);
@@ -157,10 +215,15 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
       const float sa = e.a_scale ? e.a_scale[m] : 1.0f;
       v.x *= sa * cp.wscale.x; v.y *= sa * cp.wscale.y; v.z *= sa * cp.wscale.z; v.w *= sa * cp.wscale.w;
     }
+    if (e.ln_stats) {            // folded LayerNorm: (x W'^T - mean c) rstd   (cp.scale holds c; GemmEpi::ln_c)
+      const float2 st = e.ln_stats[m];
+      v.x = fmaf(-st.x, cp.scale.x, v.x) * st.y; v.y = fmaf(-st.x, cp.scale.y, v.y) * st.y;
+      v.z = fmaf(-st.x, cp.scale.z, v.z) * st.y; v.w = fmaf(-st.x, cp.scale.w, v.w) * st.y;
+    }
     v.x += cp.bias.x; v.y += cp.bias.y; v.z += cp.bias.z; v.w += cp.bias.w;
     if (e.act == ACT_GELU) { gelu_fast4(v); }
     else if (e.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    v.x *= cp.scale.x; v.y *= cp.scale.y; v.z *= cp.scale.z; v.w *= cp.scale.w;
+    if (!e.ln_stats) { v.x *= cp.scale.x; v.y *= cp.scale.y; v.z *= cp.scale.z; v.w *= cp.scale.w; }
     size_t orow = (size_t)m;
     if (e.rows_per_img > 0) {
       const int b = m / e.rows_per_img, p = m - b * e.rows_per_img;
@@ -233,13 +296,20 @@ __device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, con
   if (n >= N) return;
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0;
   if (e.bias) { b0 = *reinterpret_cast<const float4*>(e.bias + n); b1 = *reinterpret_cast<const float4*>(e.bias + n + 4); }
-  if (e.scale) { s0 = *reinterpret_cast<const float4*>(e.scale + n); s1 = *reinterpret_cast<const float4*>(e.scale + n + 4); }
+  const bool ln = e.ln_stats != nullptr;      // folded LayerNorm: s0 / s1 hold the column sums c[n] instead of a LayerScale
+  const float* sc = ln ? e.ln_c : e.scale;
+  if (sc) { s0 = *reinterpret_cast<const float4*>(sc + n); s1 = *reinterpret_cast<const float4*>(sc + n + 4); }
 #pragma unroll
   for (int row_l = tid / C8; row_l < ROWS; row_l += NT / C8) {
     const int m = rowmap(row_l);
     if (m >= M) continue;
     float4 v = *reinterpret_cast<const float4*>(sm + row_l * pitch + c8 * 32);
     float4 u = *reinterpret_cast<const float4*>(sm + row_l * pitch + c8 * 32 + 16);
+    if (ln) {                     // (x W'^T - mean c) rstd
+      const float2 st = e.ln_stats[m];
+      v.x = fmaf(-st.x, s0.x, v.x) * st.y; v.y = fmaf(-st.x, s0.y, v.y) * st.y; v.z = fmaf(-st.x, s0.z, v.z) * st.y; v.w = fmaf(-st.x, s0.w, v.w) * st.y;
+      u.x = fmaf(-st.x, s1.x, u.x) * st.y; u.y = fmaf(-st.x, s1.y, u.y) * st.y; u.z = fmaf(-st.x, s1.z, u.z) * st.y; u.w = fmaf(-st.x, s1.w, u.w) * st.y;
+    }
     v.x += b0.x; v.y += b0.y; v.z += b0.z; v.w += b0.w;
     u.x += b1.x; u.y += b1.y; u.z += b1.z; u.w += b1.w;
     if (e.act == ACT_GELU) {
@@ -248,8 +318,10 @@ __device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, con
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
     }
-    v.x *= s0.x; v.y *= s0.y; v.z *= s0.z; v.w *= s0.w;
-    u.x *= s1.x; u.y *= s1.y; u.z *= s1.z; u.w *= s1.w;
+    if (!ln) {
+      v.x *= s0.x; v.y *= s0.y; v.z *= s0.z; v.w *= s0.w;
+      u.x *= s1.x; u.y *= s1.y; u.z *= s1.z; u.w *= s1.w;
+    }
     if (e.glu) {                    // interleaved SwiGLU pairs: eight columns -> four gated outputs at column n / 2 of an N / 2-column row
       const float4 gq = make_float4(silu_mul(v.x, v.y), silu_mul(v.z, v.w), silu_mul(u.x, u.y), silu_mul(u.z, u.w));
       const int nh = n >> 1;

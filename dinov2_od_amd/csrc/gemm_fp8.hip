@@ -320,6 +320,17 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
 static constexpr int LDS8MX = F8_SLOTS * F8_STAGE + 2 * F8_SC_BYTES;
 static constexpr int LDS8 = (128 * (F8N * 4 + 16)) > F8_SLOTS * F8_STAGE ? (128 * (F8N * 4 + 16)) : F8_SLOTS * F8_STAGE;
 
+static void fp8_attr() {      // > 64 KiB of dynamic LDS: once per DEVICE (a process may drive several)
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8MX);
+    attr_set[dev] = true;
+  }
+}
+
 int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int ldw, int M, int N, int K,
                     const GemmEpi& e, hipStream_t s) {
   if (M <= 0 || N <= 0 || K <= 0) return 1;
@@ -331,33 +342,15 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
   if (e.out_bs && (!e.glu || !e.out_bf16 || N % 128 != 0 || e.scale || e.resid || e.act != ACT_NONE)) return 2;
   if (e.a_bs) {          // block-scaled activations
     if (K % 256 != 0) return 2;
-    static bool attr_mx = false;
-    if (!attr_mx) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8MX); attr_mx = true; }
-    static const char* gmx = getenv("DINODET_GEMM_GM");
-    const int gm = gmx ? atoi(gmx) : (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2));
+    if (reinterpret_cast<uintptr_t>(e.a_bs) & 3) return 2;      // the scale bytes arrive by 4-byte LDS-DMA
+    fp8_attr();
+    const int gm = N >= 3072 ? 8 : (N >= 2048 ? 4 : 2);
     const int tiles = ((M + F8M - 1) / F8M) * ((N + F8N - 1) / F8N);
     hipLaunchKernelGGL(gemm_fp8mx_256x128_kernel, dim3(tiles), dim3(512), LDS8MX, s, A, lda, W, ldw, M, N, K, e, gm);
     return hipGetLastError() == hipSuccess ? 0 : 3;
   }
-  {
-    // the 256x256 ping-pong kernel (gemm_pp.hip) where the K loop is long enough to pay for its one-workgroup-per-CU prologue /
-    // epilogue; measured (tools/bench_fp8.py, DINODET_FP8_TILE = p / o forces either kernel): ViT-g, 32 x 518^2: QKV (K 1536) 449 vs
-    // 474 us, MLP-in (K 1536) 769 vs 772, MLP-out (K 4096) 318 vs 381 (1 733 TFLOP/s); at K = 768 (ViT-B QKV / fc1) it loses 11 %.
-    // In the ViT-g forward, forced onto every linear, it LOSES (fp8 GEMM class 75.2 vs 64.3 ms): with K loops this short the in-place fp32
-    // residual epilogue of out-proj / MLP-out (63 k cycles on a one-workgroup-per-CU kernel) outweighs the loop ; restricted to
-    // the QKV / MLP-in linears it still loses (68.8 vs 63.5 ms: in the forward their operands arrive from the producing kernels, not
-    // from a warm cache).  Kept as an opt-in (DINODET_FP8_TILE=p); the two-workgroups-per-CU kernel below stays the default
-    static const char* v = getenv("DINODET_FP8_TILE");
-    const bool pp = v && v[0] == 'p' && !e.out_bs;      // opt-in only: see above
-    if (pp && K % 128 == 0) return launch_gemm_fp8_pp(A, lda, W, ldw, M, N, K, e, s);
-  }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
-    attr_set = true;
-  }
-  static const char* gme = getenv("DINODET_GEMM_GM");
-  const int gm = gme ? atoi(gme) : (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2));
+  fp8_attr();
+  const int gm = N >= 3072 ? 8 : (N >= 2048 ? 4 : 2);
   const int tiles = ((M + F8M - 1) / F8M) * ((N + F8N - 1) / F8N);
   hipLaunchKernelGGL(gemm_fp8_256x128_kernel, dim3(tiles), dim3(512), LDS8, s, A, lda, W, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;

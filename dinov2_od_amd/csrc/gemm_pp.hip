@@ -34,144 +34,8 @@
 
 __device__ __forceinline__ int pp_swz(int row, int chunk) { return chunk ^ (((row >> 3) & 1) << 1); }   // 16x16x32 lane map, 64-B rows
 
-__global__ __launch_bounds__(512) void gemm_pp_256x256_kernel(const bf16_t* __restrict__ A, int lda,
-                                                              const bf16_t* __restrict__ W, int ldw, int M, int N,
-                                                              int K, GemmEpi e, int GM) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
-  const int grp_ = wu >> 2, wq = wu & 3;
-  const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
-  int tm, tn;
-  tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
-  const int m0 = tm * PPM, n0 = tn * PPN;
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  // staging: per plane a wave issues two 16-row pieces (rows wid*32 + {0..15}, {16..31}); lane -> (row = lane >> 2,
-  // LDS chunk slot lane & 3), fetching global chunk slot ^ swizzle(row)
-  const bf16_t *gA0, *gA1, *gW0, *gW1;
-  {
-    const int rl = wid * 32 + (lane >> 2);
-    const int c = pp_swz(rl, lane & 3);          // rows rl and rl + 16 share row bit 3
-    int ra0 = m0 + rl, ra1 = m0 + rl + 16; ra0 = ra0 < M ? ra0 : M - 1; ra1 = ra1 < M ? ra1 : M - 1;
-    int rw0 = n0 + rl, rw1 = n0 + rl + 16; rw0 = rw0 < N ? rw0 : N - 1; rw1 = rw1 < N ? rw1 : N - 1;
-    gA0 = A + (size_t)ra0 * lda + c * 8; gA1 = A + (size_t)ra1 * lda + c * 8;
-    gW0 = W + (size_t)rw0 * ldw + c * 8; gW1 = W + (size_t)rw1 * ldw + c * 8;
-  }
-  char* const sdst = smem + wu * 2048;
-  // plane pl (0: A k0, 1: A k1, 2: W k0, 3: W k1) of K-tile t -> buffer t & 1
-#define PP_STAGE(t, pl)                                                                                        \
-  {                                                                                                            \
-    char* d_ = sdst + ((t) & 1) * PP_TILE + (pl) * PP_PLANE;                                                   \
-    const int ko_ = (t) * PPK + ((pl) & 1) * 32;                                                               \
-    if ((pl) < 2) {                                                                                            \
-      __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + ko_), (lptr_t)(d_), 16, 0, 0);                           \
-      __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + ko_), (lptr_t)(d_ + 1024), 16, 0, 0);                    \
-    } else {                                                                                                   \
-      __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + ko_), (lptr_t)(d_), 16, 0, 0);                           \
-      __builtin_amdgcn_global_load_lds((gptr_t)(gW1 + ko_), (lptr_t)(d_ + 1024), 16, 0, 0);                    \
-    }                                                                                                          \
-  }
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nk = K / PPK;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  // fragment byte offsets inside a K-tile buffer (k half 0; + PP_PLANE for k half 1)
-  int offA[8], offW[4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { const int row = grp_ * 128 + i * 16 + l15; offA[i] = row * 64 + pp_swz(row, l4) * 16; }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { const int row = wq * 64 + j * 16 + l15; offW[j] = 2 * PP_PLANE + row * 64 + pp_swz(row, l4) * 16; }
-
-  // prologue: tile 0 whole, k half 0 of tile 1 (the rest follows the steady-state schedule from phase 0 on)
-  PP_STAGE(0, 0) PP_STAGE(0, 2) PP_STAGE(0, 1) PP_STAGE(0, 3)
-  if (nk > 1) { PP_STAGE(1, 0) PP_STAGE(1, 2) }
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (grp_ == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one segment behind group 0
-  asm volatile("" ::: "memory");
-
-  bf16x8 wf[4], af[4];
-  // one phase.  PF: 0 = nothing to prefetch, else the (tile, plane) staged in this LOAD segment.  VW: vmcnt immediate to wait
-  // for at the end of the LOAD segment (-1: none).
-#define PP_PHASE(st, p, PF_ON, PF_T, PF_PL, VW)                                                                \
-  {                                                                                                            \
-    constexpr int kh_ = (p) >> 1, mh_ = (p) & 1;                                                               \
-    if (mh_ == 0) {                                                                                            \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>((st) + offW[j] + kh_ * PP_PLANE); \
-    }                                                                                                          \
-    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) af[ii] = *reinterpret_cast<const bf16x8*>((st) + offA[4 * mh_ + ii] + kh_ * PP_PLANE); \
-    if (PF_ON) PP_STAGE(PF_T, PF_PL)                                                                           \
-    if ((VW) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                            \
-    else if ((VW) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                       \
-    else if ((VW) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    __builtin_amdgcn_s_barrier();                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                                             \
-    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                           \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
-        acc[4 * mh_ + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[ii], acc[4 * mh_ + ii][j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    __builtin_amdgcn_s_barrier();                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-  }
-
-  int u = 0;
-  // steady state: tiles u with u + 2 < nk
-  for (; u + 2 < nk; ++u) {
-    const char* st = smem + (u & 1) * PP_TILE;
-    PP_PHASE(st, 0, true, u + 1, 1, -1)
-    PP_PHASE(st, 1, true, u + 1, 3, 8)          // k-half-1 planes of tile u landed (4 planes issued since)
-    PP_PHASE(st, 2, true, u + 2, 0, -1)
-    PP_PHASE(st, 3, true, u + 2, 2, 8)          // k-half-0 planes of tile u + 1 landed
-  }
-  if (u + 1 < nk) {                             // second-to-last tile: nothing left to stage beyond tile u + 1
-    const char* st = smem + (u & 1) * PP_TILE;
-    PP_PHASE(st, 0, true, u + 1, 1, -1)
-    PP_PHASE(st, 1, true, u + 1, 3, 8)
-    PP_PHASE(st, 2, false, 0, 0, -1)
-    PP_PHASE(st, 3, false, 0, 0, 4)             // k-half-0 of tile u + 1; younger: its two k-half-1 planes
-    ++u;
-  }
-  {                                             // last tile
-    const char* st = smem + (u & 1) * PP_TILE;
-    PP_PHASE(st, 0, false, 0, 0, -1)
-    PP_PHASE(st, 1, false, 0, 0, 0)             // k-half-1 planes of the last tile
-    PP_PHASE(st, 2, false, 0, 0, -1)
-    PP_PHASE(st, 3, false, 0, 0, -1)
-  }
-  if (grp_ == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last barrier: every LDS read has retired
-  asm volatile("" ::: "memory");
-
-  // epilogue: two passes of 128 tile rows (64 of each group) through a 128 x 256 fp32 LDS tile (pitch +16 B)
-  constexpr int PITCH = PPN * 4 + 16;
-  const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
-  const bool wide = drain8_ok(e, N);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass) __syncthreads();
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row_l = grp_ * 64 + ii * 16 + l15;
-        const int col = wq * 64 + j * 16 + 4 * l4;
-        const f32x4 a = acc[pass * 4 + ii][j];
-        *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
-      }
-    __syncthreads();
-    if (wide) drain_tile_bf16x8<128, PPN, 512>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
-    else drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                                   [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
-  }
-}
-
+// (The first, k-phased form of this kernel -- 4 phases per K-tile along k -- was superseded by the m-phased kernels below and removed in
+// round 4; the structure notes above describe the skeleton both share.)
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // The same ping-pong structure with phases along m (quarter q = rows 32q..32q+31 of the wave's 128): every phase needs all
@@ -185,11 +49,16 @@ __global__ __launch_bounds__(512) void gemm_pp_256x256_kernel(const bf16_t* __re
 // K-tile, vmcnt(4) at the end of LOAD 3 (tile u+1 complete, the two W planes of u+2 still in flight).
 // tuning only (tools/pp_timeline.py): when non-null, lane 0 of wave 0 of every workgroup stores {s_memtime at entry, after the prologue,
 // after the K loop, at exit (stores drained), s_memrealtime at entry, at exit, blockIdx, 0}
+#ifdef DINODET_TUNING
 __device__ unsigned long long* g_pp_stamps = nullptr;
 extern "C" int dod_debug_pp_stamps(void* dev_buf) {
   unsigned long long* p = (unsigned long long*)dev_buf;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_pp_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 3;
 }
+#define PP_STAMPS_DECL unsigned long long* const stamps = g_pp_stamps;
+#else
+#define PP_STAMPS_DECL unsigned long long* const stamps = nullptr;      // release build: the stamp code folds away
+#endif
 
 // DC = true: the two LDS-DMA instructions of a phase are issued from inside the COMPUTE segment (between its MFMAs, whose issue slots
 // have slack: an MFMA holds the issue port for half its 16 cycles) instead of the LOAD segment, whose length -- not the MFMAs' --
@@ -203,7 +72,7 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
   const int wu = __builtin_amdgcn_readfirstlane(wid);
   const int grp_ = wu >> 2, wq = wu & 3;
   const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
-  unsigned long long* const stamps = g_pp_stamps;
+  PP_STAMPS_DECL
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tr0 = 0;
   if (stamps) { ts0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
   int tm, tn;
@@ -413,7 +282,7 @@ __global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __rest
   const int wu = __builtin_amdgcn_readfirstlane(wid);
   const int grp_ = wu >> 2, wq = wu & 3;
   const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
-  unsigned long long* const stamps = g_pp_stamps;
+  PP_STAMPS_DECL
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tr0 = 0;
   if (stamps) { ts0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
   int tm, tn;
@@ -601,194 +470,30 @@ __global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __rest
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// fp8 (OCP e4m3) GEMM on the same 8-wave ping-pong skeleton (the ViT-g/14 fp8 configuration, BASELINE configs[4]; replaces the
-// 256x128 two-workgroups-per-CU kernel of gemm_fp8.hip on the large shapes): K-tile = 128 k as four planes of [256 rows][64 B]
-// (A k0..63 | A k64..127 | W k0..63 | W k64..127, two 64-KiB buffers), 32x32 lane map as in the H2 kernel (lane (r, g) reads chunks
-// 2g, 2g+1 of a plane row = one v_mfma_f32_32x32x64_f8f6f4 operand; scale operands constant 0 -> the unscaled form), two phases per
-// K-tile (row blocks 2p, 2p+1: 8 MFMAs = 512 matrix-pipe cycles per COMPUTE segment), dequantisation a_scale[m] w_scale[n] in the
-// shared epilogue.  Per staged byte it needs the matrix-pipe cycles of the plain bf16 ping-pong kernel -- i.e. it runs into the
-// same per-CU global->LDS path -- at twice the FLOPs per byte.
-__global__ __launch_bounds__(512) void gemm_fp8pp_256x256_kernel(const char* __restrict__ A, int lda, const char* __restrict__ W, int ldw,
-                                                                 int M, int N, int K, GemmEpi e, int GM) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
-  const int grp_ = wu >> 2, wq = wu & 3;
-  const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
-  int tm, tn;
-  tile_map(blockIdx.x, tiles_m, tiles_n, GM, &tm, &tn);
-  const int m0 = tm * PPM, n0 = tn * PPN;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  unsigned vA0, vA1, vW0, vW1;
-  {
-    const int rl = wid * 32 + (lane >> 2);
-    const int c = h2_swz(rl, lane & 3);
-    int ra0 = m0 + rl, ra1 = m0 + rl + 16; ra0 = ra0 < M ? ra0 : M - 1; ra1 = ra1 < M ? ra1 : M - 1;
-    int rw0 = n0 + rl, rw1 = n0 + rl + 16; rw0 = rw0 < N ? rw0 : N - 1; rw1 = rw1 < N ? rw1 : N - 1;
-    vA0 = (unsigned)((size_t)ra0 * lda + c * 16); vA1 = (unsigned)((size_t)ra1 * lda + c * 16);
-    vW0 = (unsigned)((size_t)rw0 * ldw + c * 16); vW1 = (unsigned)((size_t)rw1 * ldw + c * 16);
-  }
-  const size_t bytesA = (size_t)M * lda, bytesW = (size_t)N * ldw;
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(bytesA > 0xfffffff0u ? 0xfffffff0u : bytesA), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)(bytesW > 0xfffffff0u ? 0xfffffff0u : bytesW), 0x00020000);
-  char* const sdst = smem + wu * 2048;
-  // plane pl (0: A k0..63, 1: A k64..127, 2: W k0..63, 3: W k64..127) of K-tile t -> buffer t & 1
-#define F8P_STAGE(t, pl)                                                                                       \
-  {                                                                                                            \
-    char* d_ = sdst + ((t) & 1) * PP_TILE + (pl) * PP_PLANE;                                                   \
-    const int ko_ = (t) * 128 + ((pl) & 1) * 64;                                                               \
-    if ((pl) < 2) {                                                                                            \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(d_), 16, vA0, ko_, 0, 0);                          \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(d_ + 1024), 16, vA1, ko_, 0, 0);                   \
-    } else {                                                                                                   \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(d_), 16, vW0, ko_, 0, 0);                          \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(d_ + 1024), 16, vW1, ko_, 0, 0);                   \
-    }                                                                                                          \
-  }
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int nk = K / 128;
-  const int lr = lane & 31, lg = lane >> 5;
-  int offA[4], offW[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { const int row = grp_ * 128 + i * 32 + lr; offA[i] = row * 64 + h2_swz(row, 2 * lg) * 16; }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { const int row = wq * 64 + j * 32 + lr; offW[j] = 2 * PP_PLANE + row * 64 + h2_swz(row, 2 * lg) * 16; }
-
-  F8P_STAGE(0, 0) F8P_STAGE(0, 1) F8P_STAGE(0, 2) F8P_STAGE(0, 3)
-  if (nk > 1) { F8P_STAGE(1, 2) F8P_STAGE(1, 3) }
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (grp_ == 1) __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  bf16x8 wf[2][2][2], af[2][2][2];       // [block][plane][chunk], read as ushort vectors (an int-typed read would make hipcc drain the DMA ring)
-  // PF: 0 none, 1 the two A planes of K-tile PF_T, 2 the two W planes of K-tile PF_T; VW: vmcnt at the end of the LOAD segment (-1 none)
-#define F8P_PHASE(st, p, PF, PF_T, VW)                                                                         \
-  {                                                                                                            \
-    if ((p) == 0) {                                                                                            \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-        _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                     \
-          wf[j][pl][0] = *reinterpret_cast<const bf16x8*>((st) + offW[j] + pl * PP_PLANE);                     \
-          wf[j][pl][1] = *reinterpret_cast<const bf16x8*>((st) + (offW[j] ^ 16) + pl * PP_PLANE);              \
-        }                                                                                                      \
-    }                                                                                                          \
-    _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                           \
-      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                       \
-        af[ii][pl][0] = *reinterpret_cast<const bf16x8*>((st) + offA[2 * (p) + ii] + pl * PP_PLANE);           \
-        af[ii][pl][1] = *reinterpret_cast<const bf16x8*>((st) + (offA[2 * (p) + ii] ^ 16) + pl * PP_PLANE);    \
-      }                                                                                                        \
-    if ((PF) == 1) { F8P_STAGE(PF_T, 0) F8P_STAGE(PF_T, 1) }                                                   \
-    if ((PF) == 2) { F8P_STAGE(PF_T, 2) F8P_STAGE(PF_T, 3) }                                                   \
-    if ((VW) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
-    else if ((VW) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    __builtin_amdgcn_s_barrier();                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                                             \
-    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                           \
-      _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                       \
-        const i32x8_ av = __builtin_shufflevector(__builtin_bit_cast(i32x4_, af[ii][pl][0]), __builtin_bit_cast(i32x4_, af[ii][pl][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
-          const i32x8_ wv = __builtin_shufflevector(__builtin_bit_cast(i32x4_, wf[j][pl][0]), __builtin_bit_cast(i32x4_, wf[j][pl][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
-          acc[2 * (p) + ii][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, acc[2 * (p) + ii][j], 0, 0, 0, 0, 0, 0); \
-        }                                                                                                      \
-      }                                                                                                        \
-    __builtin_amdgcn_s_setprio(0);                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    __builtin_amdgcn_s_barrier();                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-  }
-
-  int u = 0;
-  for (; u + 2 < nk; ++u) {
-    const char* st = smem + (u & 1) * PP_TILE;
-    F8P_PHASE(st, 0, 1, u + 1, -1)
-    F8P_PHASE(st, 1, 2, u + 2, 4)               // tile u + 1 complete; the two W planes of u + 2 in flight
-  }
-  if (u + 1 < nk) {
-    const char* st = smem + (u & 1) * PP_TILE;
-    F8P_PHASE(st, 0, 1, u + 1, -1)
-    F8P_PHASE(st, 1, 0, 0, 0)
-    ++u;
-  }
-  {
-    const char* st = smem + (u & 1) * PP_TILE;
-    F8P_PHASE(st, 0, 0, 0, -1)
-    F8P_PHASE(st, 1, 0, 0, -1)
-  }
-  if (grp_ == 0) __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  constexpr int PITCH = PPN * 4 + 16;
-  const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass) __syncthreads();
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) stage_acc(smem, PITCH, grp_ * 64 + ii * 32 + lr, wq * 64 + j * 32, acc[pass * 2 + ii][j], lg);
-    __syncthreads();
-    drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
-  }
-}
+// (An fp8 kernel on this skeleton -- round 2: faster than the 256x128 kernel of gemm_fp8.hip in isolation at K >= 1536, slower inside the ViT-g
+// forward, DESIGN.md section 9 -- was an opt-in and was removed in round 4.)
 
 static constexpr int LDSPP = (128 * (PPN * 4 + 16)) > 2 * PP_TILE ? (128 * (PPN * 4 + 16)) : 2 * PP_TILE;
 
-// K % 64 == 0, K >= 64
-int launch_gemm_bf16_pp(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
-  if (M <= 0 || N <= 0 || K <= 0 || K % PPK != 0) return 2;
-  if (N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || e.ldc % 4 != 0) return 2;
-  if (e.resid && e.ldr % 4 != 0) return 2;
-  if (!e.out_f32 && !e.out_bf16) return 2;
-  static bool attr_set[16] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
-    attr_set[dev] = true;
-  }
-  const int gm = gemm_tile_mode();
-  const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
-  hipLaunchKernelGGL(gemm_pp_256x256_kernel, dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
-  return hipGetLastError() == hipSuccess ? 0 : 3;
-}
-
-// weight-resident tile map (gemm_epi.h tile_map, mode bit 0x400) for the m-phased ping-pong kernels: DINODET_GEMM_WRES = 1 (read per launch)
-static bool wres_on() {
-  const char* v = getenv("DINODET_GEMM_WRES");
-  return v && v[0] == '1';
-}
+#ifdef DINODET_TUNING
+// weight-resident tile map (gemm_epi.h tile_map, mode bit 0x400): DINODET_GEMM_WRES = 1 (read per launch)
 static int wres_grid(int M, int N, int* gm) {
   const int tiles_m = (M + PPM - 1) / PPM, tiles_n = (N + PPN - 1) / PPN;
-  if (wres_on() && tiles_n % 2 == 0 && tiles_m >= 32) { *gm = (*gm & ~0x300) | 0x400; return 8 * ((tiles_m + 3) / 4) * (tiles_n / 2); }
+  const char* v = getenv("DINODET_GEMM_WRES");
+  if (v && v[0] == '1' && tiles_n % 2 == 0 && tiles_m >= 32) { *gm = (*gm & ~0x300) | 0x400; return 8 * ((tiles_m + 3) / 4) * (tiles_n / 2); }
   return tiles_m * tiles_n;
 }
+#else
+static int wres_grid(int M, int N, int*) { return ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN); }
+#endif
 
-// residual loads in flight per thread in the in-place residual epilogue of the 512-thread kernels (gemm_epi.h drain_resid):
-// DINODET_EPI_RB = 4 | 8 | 16 (read per launch: A/B in one process)
-static int epi_rb() {
-  const char* v = getenv("DINODET_EPI_RB");
-  return v ? atoi(v) : 0;
-}
-
-static void ppm_attr() {
+static void ppm_attr() {      // > 64 KiB of dynamic LDS: once per device
   static bool attr_set[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
     attr_set[dev] = true;
   }
 }
@@ -802,11 +507,7 @@ int launch_gemm_bf16_ppm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int
   ppm_attr();
   int gm = gemm_tile_mode();
   const int tiles = wres_grid(M, N, &gm);
-  const char* f_ = getenv("DINODET_GEMM_TILE");
-  GemmEpi e2 = e;
-  if (!e2.rb) e2.rb = epi_rb();
-  if (f_ && f_[0] == 'r') hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, true>), dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e2, gm);
-  else hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, false>), dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e2, gm);
+  hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, false>), dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -817,20 +518,24 @@ int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int 
   if (e.out_f32 && e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
-  GemmEpi e2 = e;
-  if (!e2.rb) e2.rb = epi_rb();
-  if (getenv("DINODET_DEBUG_NOOUT")) { e2.ldc = 0; e2.ldr = 0; }   // tuning only: every output row aliases row 0
   ppm_attr();
-  if (getenv("DINODET_DEBUG_LDA0")) lda = 0;      // tuning only: every A row aliases row 0 (A traffic becomes cache hits)
   int gm = gemm_tile_mode();
   const int tiles = wres_grid(M, N, &gm);
-  const char* v_ = getenv("DINODET_X3_TILE");
-  if (v_ && v_[0] == 'p' && v_[1] == 'd') hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, true>), dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e2, gm);
-  else hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, false>), dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e2, gm);
+  hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, false>), dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
 // H2 operands (dod_common.h): A [M, K] activation rows at pitch lda bytes (>= 4K), W [N, K] weight rows at pitch ldw bytes (>= 3K)
+static constexpr int LDSH2 = (128 * (PPN * 4 + 16)) > H2_LDS ? (128 * (PPN * 4 + 16)) : H2_LDS;
+static void h2_attr() {
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSH2);
+    attr_set[dev] = true;
+  }
+}
 int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
   if (M <= 0 || N <= 0 || K <= 0) return 1;
   if (K % 32 != 0 || N % 4 != 0 || lda % 16 != 0 || ldw % 16 != 0 || lda < 4 * K || ldw < 3 * K || !e.h2_wexp) return 2;
@@ -841,20 +546,10 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
     if (e.out_h2 && (No % 32 != 0 || e.ldc < 2 * No || e.ldc % 8 != 0 || e.out_split != 0)) return 2;
     if (e.glu && e.out_h2 && (N % 8 != 0)) return 2; }
   { const int t = gemm_tail_split(2, A, lda, W, ldw, M, N, K, e, s); if (t >= 0) return t; }
-  constexpr int LDSH2 = (128 * (PPN * 4 + 16)) > H2_LDS ? (128 * (PPN * 4 + 16)) : H2_LDS;
-  static bool attr_set[16] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSH2);
-    attr_set[dev] = true;
-  }
+  h2_attr();
   const int gm = gemm_tile_mode();
   const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
-  if (const char* v = getenv("DINODET_DEBUG_LDA0")) lda = atoi(v) & ~15;   // tuning only: A row pitch override (0: every row aliases row 0; 64: 16-row pieces contiguous)
-  GemmEpi e2 = e;
-  if (!e2.rb) e2.rb = epi_rb();
-  hipLaunchKernelGGL(gemm_h2_256x256_kernel, dim3(tiles), dim3(512), LDSH2, s, (const char*)A, lda, (const char*)W, ldw, M, N, K, e2, gm);
+  hipLaunchKernelGGL(gemm_h2_256x256_kernel, dim3(tiles), dim3(512), LDSH2, s, (const char*)A, lda, (const char*)W, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -931,20 +626,17 @@ static float* tail_slab(int dev, hipStream_t s) {
   return (float*)((char*)g_tail_scratch[dev][g_tail_gen[dev] - 1] + (size_t)pick * g_tail_bytes[dev]);
 }
 
-// mode of the split: -1 = DINODET_GEMM_TAILSPLIT from the environment (read once), 0 = off, 1 = the shipped heuristic, 2 = every
-// qualifying shape (tests).  dod_debug_set_tailsplit lets a test force the split for its own cases and hand the default back.
-static std::atomic<int> g_tail_mode{-1};
-extern "C" void dod_debug_set_tailsplit(int mode) { g_tail_mode.store(mode); }
+// mode of the split (test option DOD_OPT_TAILSPLIT): -1 / 1 = the shipped heuristic, 0 = off, 2 = every qualifying shape
 static int tail_mode() {
-  const int m = g_tail_mode.load();
+  const int m = dod_option(DOD_OPT_TAILSPLIT);
   if (m >= 0) return m;
-  static const char* env = getenv("DINODET_GEMM_TAILSPLIT");
+  static const char* env = DOD_TUNE_ENV("DINODET_GEMM_TAILSPLIT");
   return env ? (env[0] == '0' ? 0 : (env[0] == '2' ? 2 : 1)) : 1;
 }
 
 static thread_local bool t_in_tail_split = false;
-static long g_tail_splits = 0;
-extern "C" long dod_debug_tail_splits() { return g_tail_splits; }   // tuning / tests: how many GEMM calls took the split path
+static std::atomic<long> g_tail_splits{0};
+long gemm_tail_split_count() { return g_tail_splits.load(); }
 int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
   if (t_in_tail_split || e.ksplit > 1 || e.rows_per_img != 0 || e.a_scale || e.out_split > 0) return -1;
   const int mode = tail_mode();
@@ -963,9 +655,9 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   // plain bf16 (kind 0) has a 256x128 tile for underfilled grids and does NOT take this K-split by default.  Round 3 tried it on the
   // decoder's query-side linears (M = B*Q = 3 200 rows at batch 32: 39 tiles of 256x256 walking K' = 3K = 2 304, 48.5 us on 78 CUs as
   // 256x128 tiles): six slices per tile (234 workgroups) + the reduce launch write and re-read 59 MB of fp32 partials, and the forward
-  // gains nothing (`bench.py --workload vitb224`: 7 539 vs 7 571 images/s, vitb518 2 241.7 both ways).  DINODET_GEMM_KSPLIT0 = n enables it
-  // for grids of at most CUs * n / 12 tiles (tuning switch).
-  static const int k0frac = [] { const char* v = getenv("DINODET_GEMM_KSPLIT0"); return v ? atoi(v) : 0; }();
+  // gains nothing (`bench.py --workload vitb224`: 7 539 vs 7 571 images/s, vitb518 2 241.7 both ways).  Tuning builds: DINODET_GEMM_KSPLIT0 = n
+  // enables it for grids of at most CUs * n / 12 tiles.
+  static const int k0frac = [] { const char* v = DOD_TUNE_ENV("DINODET_GEMM_KSPLIT0"); return v ? atoi(v) : 0; }();
   if (M >= 2048 && (kind >= 1 ? tiles * 2 <= CU + CU / 8 : tiles * 12 <= CU * k0frac)) {
     // (a) an UNDERFILLED single round (the compensated kernels have no smaller tile): 99 tiles of an N = 768 GEMM at M = 8224 leave 157
     // CUs idle -- every tile is K-split so that tiles x S fills the chip (no main launch)
@@ -1015,9 +707,7 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   es.ksplit = S; es.kslice_len = K / S; es.kslice_stride = (long long)slab;
   const int gm = gemm_tile_mode() & 0xfff;          // no start stagger
   if (kind == 2) {
-    constexpr int LDSH2 = (128 * (PPN * 4 + 16)) > H2_LDS ? (128 * (PPN * 4 + 16)) : H2_LDS;
-    static bool a2[16] = {};
-    if (!a2[dev]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSH2); a2[dev] = true; }
+    h2_attr();
     const char* Ar = (const char*)A + (size_t)Mmain * lda;
     hipLaunchKernelGGL(gemm_h2_256x256_kernel, dim3(tiles_r, S), dim3(512), LDSH2, s, Ar, lda, (const char*)W, ldw, R, N, K, es, gm);
   } else {
@@ -1030,21 +720,5 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   // ---- reduce + the caller's epilogue on global rows Mmain..M-1
   ++g_tail_splits;
   hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3((R + KSR_ROWS - 1) / KSR_ROWS, tiles_n), dim3(512), 0, s, scratch, (long long)slab, S, R, N, e, Mmain, M);
-  return hipGetLastError() == hipSuccess ? 0 : 3;
-}
-
-// fp8 (e4m3) operands, one byte per element, row pitches lda / ldw bytes; K % 128 == 0; e.a_scale / e.w_scale set
-int launch_gemm_fp8_pp(const unsigned char* A, int lda, const unsigned char* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
-  if (M <= 0 || N <= 0 || K <= 0 || K % 128 != 0) return 2;
-  static bool attr_set[16] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8pp_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
-    attr_set[dev] = true;
-  }
-  const int gm = gemm_tile_mode();
-  const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
-  hipLaunchKernelGGL(gemm_fp8pp_256x256_kernel, dim3(tiles), dim3(512), LDSPP, s, (const char*)A, lda, (const char*)W, ldw, M, N, K, e, gm);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -112,19 +112,21 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
   constexpr int PITCH = X3N * 4 + 16;
   const ColParams cp = load_col_params<X3N>(e, n0, N, tid);
   const bool wide = drain8_ok(e, N);
-#pragma unroll
+  // (the pass loop stays ROLLED -- one copy of the drain code -- and the accumulators are staged from statically indexed registers in
+  // either branch: left to the unroller, a body that outgrows its threshold turns `acc[pass * 2 + ii]` into a scratch array)
+#define X3_STAGE_ACC(P)                                                                                                     \
+  _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                         \
+      const int row_l = wm * 32 + ii * 16 + l15;                                                                            \
+      const int col = wn * 64 + j * 16 + 4 * l4;                                                                            \
+      const f32x4 a = acc[(P) * 2 + ii][j];                                                                                 \
+      *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);                     \
+    }
+#pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row_l = wm * 32 + ii * 16 + l15;
-        const int col = wn * 64 + j * 16 + 4 * l4;
-        const f32x4 a = acc[pass * 2 + ii][j];
-        *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
-      }
+    if (pass == 0) { X3_STAGE_ACC(0) } else { X3_STAGE_ACC(1) }
     __syncthreads();
     if (wide) drain_tile_bf16x8<128, X3N, 1024>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
     else drain_tile<128, X3N, 1024>(smem, PITCH, e, cp, M, N, n0, tid,
@@ -132,16 +134,16 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
   }
 }
 
-// tile-order mode of the 256x256 kernels (gemm_epi.h tile_map): DINODET_GEMM_GM = group depth, DINODET_GEMM_ORDER = bit 0 reverse,
-// bit 1 chunked (tuning switches, read per call)
+// tile-order mode of the 256x256 kernels (gemm_epi.h tile_map): group depth 4, time-ordered ("chunked") map.  Tuning builds: DINODET_GEMM_GM =
+// group depth, DINODET_GEMM_ORDER = bit 0 reverse, bit 1 chunked, DINODET_GEMM_STAGGER = "groups,step_us" (read per call)
 int gemm_tile_mode() {
-  const char* g = getenv("DINODET_GEMM_GM");
-  const char* o = getenv("DINODET_GEMM_ORDER");
+  const char* g = DOD_TUNE_ENV("DINODET_GEMM_GM");
+  const char* o = DOD_TUNE_ENV("DINODET_GEMM_ORDER");
   int gm = g ? atoi(g) : 4;
   if (gm < 1 || gm > 64) gm = 4;
   const int ord = o ? atoi(o) : 2;        // default: time-ordered map (measured +5 % on QKV / fc2, +3-5 % on out-proj at M = 87680)
   int st = 0;
-  if (const char* sg = getenv("DINODET_GEMM_STAGGER")) {     // "groups,step_us" (tuning switch)
+  if (const char* sg = DOD_TUNE_ENV("DINODET_GEMM_STAGGER")) {     // "groups,step_us" (tuning switch)
     int G = 0; float us = 0.f;
     if (sscanf(sg, "%d,%f", &G, &us) == 2 && G >= 2 && G <= 16 && us > 0.f) {
       int step = (int)(us / 0.16f + 0.5f); step = step < 1 ? 1 : (step > 0xfff ? 0xfff : step);
@@ -152,6 +154,17 @@ int gemm_tile_mode() {
 }
 
 static constexpr int LDSX3 = (128 * (X3N * 4 + 16)) > X3_SLOTS * X3_STAGE ? (128 * (X3N * 4 + 16)) : X3_SLOTS * X3_STAGE;
+
+static void x3_attr() {      // > 64 KiB of dynamic LDS: once per device
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
+    attr_set[dev] = true;
+  }
+}
 
 // A2 [M, lda >= 2K], W2 [N, ldw >= 2K]: pair layout; K % 32 == 0
 int launch_gemm_x3(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, int N, int K, const GemmEpi& e,
@@ -165,17 +178,12 @@ int launch_gemm_x3(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, 
   {
     // the 8-wave ping-pong kernel (gemm_pp.hip) wherever a workgroup's K loop or column count is long enough to pay for its
     // 512-thread epilogue: measured at M = 87680 against the 16-wave kernel below -- QKV 400 vs 378, fc1 376 vs 363, fc2 406 vs 371
-    // TFLOP/s algorithmic; out-proj (N = K = 768) 276 vs 293, so that one stays.  DINODET_X3_TILE = p / w forces either.
-    const char* v = getenv("DINODET_X3_TILE");
+    // TFLOP/s algorithmic; out-proj (N = K = 768) 276 vs 293, so that one stays.  (tuning builds: DINODET_X3_TILE = p / w forces either)
+    const char* v = DOD_TUNE_ENV("DINODET_X3_TILE");
     const bool pp = v ? v[0] == 'p' : (M >= 4096 && (N >= 1536 || K >= 2048));
     if (pp) return launch_gemm_x3_pp(A2, lda, W2, ldw, M, N, K, e, s);
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
-    attr_set = true;
-  }
+  x3_attr();
   const int gm = gemm_tile_mode();
   const int tiles = ((M + X3M - 1) / X3M) * ((N + X3N - 1) / X3N);
   hipLaunchKernelGGL(gemm_x3_256x256_kernel<false>, dim3(tiles), dim3(1024), LDSX3, s, A2, lda, W2, ldw, M, N, K, e, gm);
@@ -185,11 +193,7 @@ int launch_gemm_x3(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, 
 // plain bf16 GEMM on the same structure (256x256x64, 16 waves, two 64-KiB slots): K % 64 == 0
 int launch_gemm_bf16_k64(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 64 != 0) return 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
-    attr_set = true;
-  }
+  x3_attr();
   const int gm = gemm_tile_mode();
   const int tiles = ((M + X3M - 1) / X3M) * ((N + X3N - 1) / X3N);
   hipLaunchKernelGGL(gemm_x3_256x256_kernel<true>, dim3(tiles), dim3(1024), LDSX3, s, A, lda, W, ldw, M, N, K, e, gm);

@@ -175,6 +175,156 @@ int launch_layernorm(const float* x, const float* add, const float* gamma, const
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
+// ----------------------------------------------------------------------------- folded LayerNorm (GemmEpi::ln_*, dod_common.h)
+// The backbone's pre-norm LayerNorms (modeling_dinov2.py:348, 353) are folded into the GEMMs around them: the residual GEMM that produces a
+// row also writes it in the next GEMM's operand format and its (sum, centred square sum) per 128-column group; the next GEMM normalises
+// in its epilogue.  What is left as kernels of their own: the first block's input (rowstats_kernel: its producer is the patch embedding),
+// the merge of the group statistics (ln_finalize_kernel) and the one-time weight fold.
+template <int NCH, bool EXACT, int KIND>
+__global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__ x, int rows, int D, float eps, void* __restrict__ op, float2* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nc = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+  float4 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (EXACT || c < nc) { v[i] = xr[c]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (EXACT || c < nc) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) stats[row] = make_float2(mean, rstd);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (!(EXACT || c < nc)) continue;
+    const float4 w = v[i];
+    if (KIND == LNOP_H2) {
+      uint2 f16; unsigned hi8, lo8;
+      h2_quad(w, 1.0f, f16, hi8, lo8);
+      char* ob = reinterpret_cast<char*>(op) + (size_t)row * 4 * D;
+      reinterpret_cast<uint2*>(ob)[c] = f16;
+      char* p8 = ob + h2_off8(D, 4 * c);
+      *reinterpret_cast<unsigned*>(p8) = hi8;
+      *reinterpret_cast<unsigned*>(p8 + 16) = lo8;
+    } else {
+      uint2 hi;
+      hi.x = pack2bf(w.x, w.y);
+      hi.y = pack2bf(w.z, w.w);
+      bf16_t* ob = reinterpret_cast<bf16_t*>(op) + (size_t)row * (KIND == LNOP_PAIR ? 2 : 1) * D;
+      reinterpret_cast<uint2*>(ob)[c] = hi;
+      if (KIND == LNOP_PAIR) {
+        uint2 lo;
+        lo.x = pack2bf(w.x - __uint_as_float(hi.x << 16), w.y - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = pack2bf(w.z - __uint_as_float(hi.y << 16), w.w - __uint_as_float(hi.y & 0xffff0000u));
+        reinterpret_cast<uint2*>(ob + D)[c] = lo;
+      }
+    }
+  }
+}
+
+template <int KIND>
+static void rowstats_dispatch(const float* x, int rows, int D, float eps, void* op, float2* stats, hipStream_t s) {
+  const dim3 grid((rows + 3) / 4), block(256);
+  const int nc = D >> 2, nch = (nc + 63) / 64;
+  const bool exact = nc == 64 * nch;
+#define RS_GO(N, E) hipLaunchKernelGGL((rowstats_kernel<N, E, KIND>), grid, block, 0, s, x, rows, D, eps, op, stats)
+  if (exact && nch == 3) RS_GO(3, true);
+  else if (exact && nch == 4) RS_GO(4, true);
+  else if (exact && nch == 6) RS_GO(6, true);
+  else if (nch <= 2) RS_GO(2, false);
+  else if (nch <= 4) RS_GO(4, false);
+  else RS_GO(LN_MAXC, false);
+#undef RS_GO
+}
+
+int launch_rowstats(const float* x, int rows, int D, float eps, void* op, int op_kind, float2* stats, hipStream_t s) {
+  if (rows <= 0) return 1;
+  if (D % 4 != 0 || D > 256 * LN_MAXC || !op || !stats) return 2;
+  if (op_kind == LNOP_H2) { if (D % 32) return 2; rowstats_dispatch<LNOP_H2>(x, rows, D, eps, op, stats, s); }
+  else if (op_kind == LNOP_PAIR) rowstats_dispatch<LNOP_PAIR>(x, rows, D, eps, op, stats, s);
+  else if (op_kind == LNOP_BF16) rowstats_dispatch<LNOP_BF16>(x, rows, D, eps, op, stats, s);
+  else return 2;
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// group statistics -> (mean, rstd): mean = sum_g sum_g / D;  M2 = sum_g [ sq_g + n_g (mean_g - mean)^2 ]  (exact merge of centred sums)
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, int npart, int rows, int D, float eps, float2* __restrict__ stats) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const float2* p = part + (size_t)row * npart;
+  float tot = 0.f;
+  for (int g = 0; g < npart; ++g) tot += p[g].x;
+  const float mean = tot / (float)D;
+  float m2 = 0.f;
+  for (int g = 0; g < npart; ++g) {
+    const int ng = (D - 128 * g) < 128 ? (D - 128 * g) : 128;
+    const float d = p[g].x / (float)ng - mean;
+    m2 += p[g].y + (float)ng * d * d;
+  }
+  stats[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)D + eps));
+}
+
+int launch_ln_finalize(const float2* part, int npart, int rows, int D, float eps, float2* stats, hipStream_t s) {
+  if (rows <= 0) return 1;
+  if (npart != (D + 127) / 128 || !part || !stats) return 2;
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, part, npart, rows, D, eps, stats);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// pack time, a wave per output feature n:  Wout[n][k] = W[n][k] gamma[k],  bias_out[n] = bias_in[n] + sum_k W[n][k] beta[k]
+__global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ W, int rows, int cols, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ bias_in, float* __restrict__ Wout, float* __restrict__ bias_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= rows) return;
+  float acc = 0.f;
+  for (int k = lane; k < cols; k += 64) {
+    const float w = W[(size_t)n * cols + k];
+    acc = fmaf(w, beta[k], acc);
+    Wout[(size_t)n * cols + k] = w * gamma[k];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) bias_out[n] = bias_in[n] + acc;
+}
+
+int launch_ln_fold(const float* W, int rows, int cols, const float* gamma, const float* beta, const float* bias_in, float* Wout, float* bias_out, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 1;
+  hipLaunchKernelGGL(ln_fold_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, W, rows, cols, gamma, beta, bias_in, Wout, bias_out);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ W, int rows, int cols, int round_bf16, float* __restrict__ c) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= rows) return;
+  float acc = 0.f;
+  for (int k = lane; k < cols; k += 64) {
+    const float w = W[(size_t)n * cols + k];
+    acc += round_bf16 ? bf2f(f2bf(w)) : w;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) c[n] = acc;
+}
+
+int launch_rowsum(const float* W, int rows, int cols, int round_bf16, float* c, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 1;
+  hipLaunchKernelGGL(rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, W, rows, cols, round_bf16, c);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 // ----------------------------------------------------------------------------- im2col for Conv2d(3->D, k=p, s=p)
 // A[m][k]: m = b*gh*gw + py*gw + px, k = c*p*p + i*p + j  (weight.reshape(D, 3*p*p) order,
 // modeling_dinov2.py:139,148).  Thread per output element; consecutive k within an (c,i) run read

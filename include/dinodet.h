@@ -206,6 +206,23 @@ int dod_op_attention_x3(const void* qkv2, void* ctx2, int B, int N, int heads, f
 int dod_op_split_h2(const float* x, int ld, int rows, int cols, void* out, void* wexp, void* stream);
 int dod_op_linear_h2(const void* A, const void* W, const void* wexp, int M, int N, int K, const float* bias, const float* scale,
                      const float* resid, int ldr, void* out, int out_layout, int ldc, int act, void* stream);
+/* LayerNorm folded into the GEMMs around it (the fast modes' schedule of modeling_dinov2.py:361-380, x -> LN -> linear): with
+ * W' = W diag(gamma), c[n] = sum_k W'[n][k] and b' = b + W beta,   LN(x) W^T + b = rstd (x W'^T - mean c) + b'.
+ *   consumer (stats, csum set): A holds the residual rows x themselves in the family's operand format, W holds W', bias holds b';
+ *   producer (part set; out_layout 0 with a residual): beside the fp32 rows it writes them in the family's operand format to op_out
+ *     ([M, N] bf16 / pair layout [M, 2N] / H2 rows) and (sum, centred sum of squares) per 128-column group to part [M][ceil(N / 128)][2];
+ * dod_op_ln_finalize merges the groups into stats [M][2] = (mean, rstd); dod_op_rowstats: x -> operand copy + stats (the first block).
+ * family: DOD_PREC_BF16 / DOD_PREC_BF16X3 / DOD_PREC_FP16X2; A / W / wexp / out_layout as in dod_op_linear / _x3 / _h2 (bf16: lda = ldw = K). */
+typedef struct dod_ln_fold {
+  const void* stats;
+  const float* csum;
+  void* op_out;
+  void* part;
+} dod_ln_fold;
+int dod_op_linear_ln(int family, const void* A, const void* W, const void* wexp, int M, int N, int K, const float* bias, const float* scale,
+                     const float* resid, int ldr, void* out, int out_layout, int ldc, int act, const dod_ln_fold* ln, void* stream);
+int dod_op_rowstats(const float* x, int rows, int D, float eps, void* op_out, int family, void* stats, void* stream);
+int dod_op_ln_finalize(const void* part, int rows, int D, float eps, void* stats, void* stream);
 /* out = LayerNorm(x + add) ; add may be NULL */
 int dod_op_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, void* out, int out_dtype, void* stream);
@@ -355,37 +372,28 @@ int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_pa
                                      const void* tape, size_t tape_bytes, const dod_bb_tail_params* grads, void* workspace,
                                      size_t workspace_bytes, void* stream);
 
-/* Tuning aid: when dev_buf is non-NULL the large bf16 GEMM kernel stores 4 x uint64 per workgroup
- * {realtime at start, after the K loop, at exit, blockIdx} (100 MHz s_memrealtime); NULL switches it off.
- * Used by tools/gemm_timeline.py. */
 /* Scratch of the GEMMs' wave-quantisation tail split (K-split partial slabs; gemm_pp.hip).  dod_finalize_weights reserves 64 MiB on the
  * current device; operator-level callers (tests, tools) reserve it themselves.  Never allocated inside a forward / stream capture. */
 int dod_reserve_gemm_scratch(size_t bytes);
-long dod_debug_tail_splits(void);   /* number of GEMM calls that took the tail-split path so far (tests) */
-/* mode of the tail split: -1 the DINODET_GEMM_TAILSPLIT environment default (the shipped heuristic when unset), 0 off, 1 heuristic,
- * 2 every qualifying shape (tests force it for their own cases and hand -1 back) */
-void dod_debug_set_tailsplit(int mode);
-/* decoder schedule: 1 = the producers of the query-side linears' operands (LayerNorm, the fp32 attention and sampling kernels, linear1's ReLU
- * epilogue) write the bf16x3 operand themselves, 0 = a split3 launch per linear (the round-2 schedule), -1 = DINODET_DEC_FUSED_SPLIT from
- * the environment (default 1).  Both schedules produce the same bits (tests/test_gpu_forward.py). */
-void dod_debug_set_dec_fused_split(int mode);
-int dod_debug_gemm_stamps(void* dev_buf);
-/* same for the ping-pong kernels (gemm_pp.hip): 8 x uint64 per workgroup, shader cycles (tools/pp_timeline.py) */
-int dod_debug_pp_stamps(void* dev_buf);
-/* same for the bf16 attention kernel: {shader cycles in the tile loop, cycles waiting for DMA + barrier, tiles, active} */
-int dod_debug_attn_stamps(void* dev_buf);
-/* register-only MFMA loop (shape 16: v_mfma_f32_16x16x32_bf16 x 8 chains, 32: 32x32x16 x 4 chains, 2: v_mfma_f32_32x32x2_f32 x 4 chains, 1: the same as one dependent chain; iters < 0: random operands), `blocks` workgroups of
- * 4 waves, `iters` rounds; dev_out[block*4 + {0,1}] = {shader cycles, 100-MHz ticks}.  Measures the SUSTAINED matrix rate and
- * clock of the part under MFMA load (tools/mfma_peak.py); not used by the forward. */
-int dod_debug_mfma_peak(int shape, int iters, int blocks, void* dev_out, void* stream);
-/* MFMA / VALU co-issue probe: per iteration 4 independent 32x32x16 MFMAs (mode & 1) and nvalu (16 | 28 | 56) independent
- * v_fma_f32 (mode & 2), interleaved; dev_out[block*4] = shader cycles of wave 0 (tools/mfma_peak.py). */
-int dod_debug_mfma_valu_probe(int nvalu, int mode, int iters, int blocks, void* dev_out, void* stream);
+/* Test hooks.  Process-wide integer options a parity test sets for its own cases and hands back with -1 (= the shipped behaviour); they
+ * are NOT environment variables -- nothing outside the calling process can change which kernel runs:
+ *   "tailsplit"        GEMM wave-quantisation tail split: 0 off, 1 the shipped heuristic, 2 every qualifying shape
+ *   "dec_fused_split"  0 = a split3 launch per decoder query-side linear (the round-2 schedule; bit-identical to the shipped one)
+ *   "mha_chunk_images" training-step attention: images per pass (forces ragged passes on small shapes)
+ *   "no_fused_patch"   1 = the explicit im2col + GEMM patch embedding (read by dod_finalize_weights)
+ *   "ln_fold"          0 = LayerNorm kernels instead of the folded form (read by dod_finalize_weights)
+ *   "deterministic"    1 = ordered reductions instead of fp32 atomics in the training step's weight gradients (also DINODET_DETERMINISTIC=1)
+ * dod_test_counter("tail_splits"): GEMM calls that took the tail-split path so far; -1 for an unknown name.
+ * The in-kernel time stamps, the register-only MFMA probes and every tile / schedule override of the tuning rounds exist only in
+ * -DDINODET_TUNING builds (include/dinodet_tuning.h); the release library exports none of them. */
+int dod_test_set_option(const char* name, int value);
+long dod_test_counter(const char* name);
 
 const char* dod_version(void);
 /* ABI revision of this header: bumped whenever an exported signature or struct layout changes (round 2's dod_set_weight gained its
- * dtype argument at revision 2; revision 3 = this file).  A C caller compiled against DOD_ABI_VERSION checks it once at load. */
-#define DOD_ABI_VERSION 3
+ * dtype argument at revision 2; revision 4 = this file: the dod_debug_* entry points left the release library, dod_test_* replaced the three
+ * the tests use, the folded-LayerNorm operators arrived).  A C caller compiled against DOD_ABI_VERSION checks it once at load. */
+#define DOD_ABI_VERSION 4
 int dod_abi_version(void);
 /* Devices visible to the HIP runtime libdinodet.so is bound to (<= 0: none / error).  The host uses it to
  * verify the library shares PyTorch's HIP runtime (pointers and streams cross this ABI). */

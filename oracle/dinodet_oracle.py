@@ -38,7 +38,20 @@ import math
 import torch
 import torch.nn.functional as F
 
-from dinov2_od_amd.config import BackboneConfig, DecoderConfig, spatial_factor
+from dinov2_od_amd.config import BackboneConfig, DecoderConfig      # shape containers only: no arithmetic of the product is imported
+
+
+def spatial_factor(hw):
+    """K16, the oracle's own restatement of dino_detector/models/deformable_attention.py:241-256: the token count hw (CLS included) is
+    used as is when it is a perfect square, else split as (i, hw / i) with i the largest divisor <= floor(sqrt(hw)) -- 257 -> (1, 257),
+    1370 -> (10, 137).  (i = 1 always divides, so the reference's "approximate" fallback is unreachable.)"""
+    side = math.isqrt(hw)
+    if side * side == hw:
+        return side, side
+    i = side
+    while hw % i:
+        i -= 1
+    return i, hw // i
 
 
 def _t(x, dtype):
@@ -140,6 +153,31 @@ def _maybe_lora_linear(sd, prefix, x, alpha, emu, fp8=False):
     return _linear(x, sd(prefix + ".weight"), sd(prefix + ".bias"), emu, fp8)
 
 
+def _eff_weight(sd, prefix, alpha):
+    """(W, b) of an nn.Linear, or the merged W + alpha * B A of a LoraLinear (what the HIP path packs)"""
+    if sd.has(prefix + ".linear.weight"):
+        return (sd(prefix + ".linear.weight") + alpha * (sd(prefix + ".lora_B.weight") @ sd(prefix + ".lora_A.weight")),
+                sd(prefix + ".linear.bias"))
+    return sd(prefix + ".weight"), sd(prefix + ".bias")
+
+
+def _ln_linear_folded(h, gamma, beta, eps, w, b, emu):
+    """linear(LayerNorm(h)) as the HIP fast modes evaluate it since round 4 (csrc/dod_common.h GemmEpi::ln_*): the GEMM reads the residual
+    row h itself in its operand format against W' = W diag(gamma) and normalises in its epilogue,
+        rstd (h W'^T - mean c) + (b + W beta),   c[n] = sum_k W'[n][k] (of the bf16-rounded elements in the single-pass bf16 mode),
+    mean / rstd from the fp32 row.  Same value as the unfolded form in exact arithmetic; the ROUNDING POINTS are what is emulated."""
+    mu = h.mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(((h - mu) ** 2).mean(-1, keepdim=True) + eps)
+    wp = w * gamma
+    bp = b + w @ beta
+    if emu == "fp16x2":
+        acc, c = _h2_product(h, wp), wp.sum(-1)
+    else:
+        wr = _bf(wp)
+        acc, c = _bf(h) @ wr.t(), wr.sum(-1)
+    return (acc - mu * c) * rstd + bp
+
+
 def _layernorm(x, w, b, eps):
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
@@ -202,7 +240,7 @@ def bicubic_resize_ref(src, out_h, out_w):
 
 
 def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float32,
-                     emulate_bf16=False, prefix="backbone.", taps=None):
+                     emulate_bf16=False, prefix="backbone.", taps=None, fold_ln=True):
     """-> features [B, N, out_dim] (CLS token included: dinov2_backbone.py:60-61)."""
     sd = _SD(sd_raw, dtype)
     emu_lin = emulate_bf16                                   # the four linears of every block
@@ -232,11 +270,17 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
         lp = f"{prefix}dino.encoder.layer.{i}."
         a = bb.lora_alpha
         # K3-K6   modeling_dinov2.py:361-370
-        y = _layernorm(h, sd(lp + "norm1.weight"), sd(lp + "norm1.bias"), bb.ln_eps)
         f8 = emu == "fp8"   # fp8 mode: QKV / out-proj / MLP-in (/ SwiGLU MLP-out) linears on e4m3 operands, the rest as the bf16 mode
-        q = _maybe_lora_linear(sd, lp + "attention.attention.query", y, a, emu_lin, f8)
-        k = _maybe_lora_linear(sd, lp + "attention.attention.key", y, a, emu_lin, f8)
-        v = _maybe_lora_linear(sd, lp + "attention.attention.value", y, a, emu_lin, f8)
+        fold = emu_lin in (True, "fp16x2") and fold_ln      # bf16 / fp16x2 emulation: norm1 / norm2 folded into the GEMM that follows
+        if fold:
+            g1, b1 = sd(lp + "norm1.weight"), sd(lp + "norm1.bias")
+            q, k, v = (_ln_linear_folded(h, g1, b1, bb.ln_eps, *_eff_weight(sd, lp + "attention.attention." + nm, a), emu_lin)
+                       for nm in ("query", "key", "value"))
+        else:
+            y = _layernorm(h, sd(lp + "norm1.weight"), sd(lp + "norm1.bias"), bb.ln_eps)
+            q = _maybe_lora_linear(sd, lp + "attention.attention.query", y, a, emu_lin, f8)
+            k = _maybe_lora_linear(sd, lp + "attention.attention.key", y, a, emu_lin, f8)
+            v = _maybe_lora_linear(sd, lp + "attention.attention.value", y, a, emu_lin, f8)
         if emu:
             q, k, v = _bf(q), _bf(k), _bf(v)
         q = q.view(B, N, nh, dh).transpose(1, 2)
@@ -259,9 +303,11 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
         if taps is not None and i == 0:
             taps["block0_attn"] = h.clone()
         # K7 / K7g   modeling_dinov2.py:373-380
-        y = _layernorm(h, sd(lp + "norm2.weight"), sd(lp + "norm2.bias"), bb.ln_eps)
+        y = None if fold else _layernorm(h, sd(lp + "norm2.weight"), sd(lp + "norm2.bias"), bb.ln_eps)
+        mlp_in = (lambda nm: _ln_linear_folded(h, sd(lp + "norm2.weight"), sd(lp + "norm2.bias"), bb.ln_eps, *_eff_weight(sd, lp + nm, a), emu_lin)) if fold \
+            else (lambda nm: _maybe_lora_linear(sd, lp + nm, y, a, emu_lin, f8))
         if bb.swiglu:
-            z = _maybe_lora_linear(sd, lp + "mlp.weights_in", y, a, emu_lin, f8)
+            z = mlp_in("mlp.weights_in")
             x1, x2 = z.chunk(2, dim=-1)
             z = F.silu(x1) * x2
             if f8 and z.shape[-1] % 256 == 0:
@@ -272,7 +318,7 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
                     z = _bf(z)          # other widths: bf16 hidden rows, then one scale per row
                 z = _maybe_lora_linear(sd, lp + "mlp.weights_out", z, a, emu_lin, f8)
         else:
-            z = _maybe_lora_linear(sd, lp + "mlp.fc1", y, a, emu_lin, f8)
+            z = mlp_in("mlp.fc1")
             z = 0.5 * z * (1.0 + torch.erf(z / math.sqrt(2.0)))   # exact-erf GELU
             z = _maybe_lora_linear(sd, lp + "mlp.fc2", z, a, emu_lin)
         h = z * sd(lp + "layer_scale2.lambda1") + h

@@ -350,7 +350,13 @@ def g9_gradients():
               ("g9_grad_cfg1_dense", "facebook/dinov2-small", 224, 2,
                dict(num_classes=91, hidden_dim=256, num_queries=25, num_decoder_layers=2, dim_feedforward=512, lora_r=1, nheads=4, dropout=0.0,
                     use_deformable=False))]
+    # the same ViT-B case evaluated by the reference's own modules in float64 (`.double()`: plain PyTorch on the CPU): the arbiter between two
+    # fp32 evaluations of an ill-conditioned gradient (three tied layers whose sampling gradient is piecewise smooth)
+    cases_.append(("g9_grad_vitb_224_f64", "facebook/dinov2-base", 224, 2, dict(num_queries=100, dropout=0.0)))
     for name, model_name, R, B, kwargs in cases_:
+        if G9_ONLY and name not in G9_ONLY:
+            continue
+        f64 = name.endswith("_f64")
         hid = kwargs.get("hidden_dim", 768)
         bb = BackboneConfig.from_name(model_name, lora_r=kwargs.get("lora_r", 2), lora_alpha=1.0, target_dim=hid)
         _BB_FOR_PATCH["bb"] = bb
@@ -363,8 +369,11 @@ def g9_gradients():
         m.train()
         x = torch.from_numpy(synth.make_pixels(B, R, R, seed=0))
         gl, gb = g9_loss_weights(B, dc.num_queries, dc.num_classes)
+        gl, gb = torch.from_numpy(gl), torch.from_numpy(gb)
+        if f64:
+            m, x, gl, gb = m.double(), x.double(), gl.double(), gb.double()
         o = m(x)
-        loss = (o["pred_logits"] * torch.from_numpy(gl)).sum() + (o["pred_boxes"] * torch.from_numpy(gb)).sum()
+        loss = (o["pred_logits"] * gl).sum() + (o["pred_boxes"] * gb).sum()
         loss.backward()
         arrs = dict(pred_logits=o["pred_logits"].detach().numpy(), pred_boxes=o["pred_boxes"].detach().numpy(), loss=np.array(float(loss)))
         names, nograd = [], []
@@ -382,6 +391,8 @@ def g9_gradients():
         _save(name, **arrs)
         print(f"{name}: {len(names)} gradients, {len(nograd)} trainable tensors the loss does not reach: {nograd}")
 
+
+G9_ONLY = [n for n in os.environ.get("G9_ONLY", "").split(",") if n]      # regenerate single G9 cases (the float64 one takes minutes)
 
 CASES = dict(g0=lambda: g0_micro_backbone(False), g4=lambda: g0_micro_backbone(True),
              g1=g1_decoder_only, g2=g2_cfg1, g3=g3_vitb, g5=g5_postprocess, g6=g6_matcher, g7=g7_vitl, g8=g8_vitg, g9=g9_gradients)

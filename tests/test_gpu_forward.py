@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from dinov2_od_amd import synth
+from dinov2_od_amd import _native as nat, synth
 from dinov2_od_amd.config import num_tokens
 from oracle import dinodet_oracle as orc
 from tests import cases
@@ -453,12 +453,12 @@ def test_decoder_fused_operand_split_is_bit_identical(G, deform, Hd, precision):
     outs = {}
     try:
         for mode in (0, 1):
-            nat.lib().dod_debug_set_dec_fused_split(mode)
+            nat.set_option("dec_fused_split", mode)
             o = m(G.to_gpu(mem))
             G.sync()
             outs[mode] = {k: v.cpu().numpy().copy() for k, v in o.items()}
     finally:
-        nat.lib().dod_debug_set_dec_fused_split(-1)
+        nat.set_option("dec_fused_split", -1)
     for k in ("pred_logits", "pred_boxes"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
     want_l, want_b = orc.decoder_forward(sd, dc, torch.from_numpy(mem).to(torch.bfloat16).float() if precision == "bf16" else torch.from_numpy(mem),
@@ -648,9 +648,9 @@ def test_reference_point_conditioning_sweep(G, precision):
 
 @pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("R", [70, 56, 224])
-def test_fused_patch_embed_matches_the_explicit_im2col_path(G, precision, R, monkeypatch):
+def test_fused_patch_embed_matches_the_explicit_im2col_path(G, precision, R):
     """K1 + K2 as ONE kernel (implicit im2col, patch_embed.hip) against the im2col + GEMM pair it replaces
-    (DINODET_NO_FUSED_PATCH=1 at weight-pack time): same products, a different fp32 summation order -> 1e-6; and against the
+    (test option "no_fused_patch" at weight-pack time): same products, a different fp32 summation order -> 1e-6; and against the
     reference's embeddings (golden G0) where a fixture exists."""
     from dinov2_od_amd.models import DINOv2Backbone
     bb = cases.micro_bb(False) if R != 224 else cases.cfg1(25)[0]
@@ -659,15 +659,17 @@ def test_fused_patch_embed_matches_the_explicit_im2col_path(G, precision, R, mon
     N = num_tokens(R, R)
     embs = {}
     for fused in (True, False):
-        if not fused:
-            monkeypatch.setenv("DINODET_NO_FUSED_PATCH", "1")
-        m = DINOv2Backbone("micro" if R != 224 else "facebook/dinov2-small", lora_r=bb.lora_r, lora_alpha=1.0, target_dim=bb.target_dim or None,
-                           pretrained=False, precision=precision, config=bb)
-        G.load_np_state(m, sd)
-        m = m.to(G.dev()).eval()
-        tap = m._get_engine().set_tap(0, (3, N, bb.hidden), "cuda:0")
-        m(x)
-        G.sync()
+        nat.set_option("no_fused_patch", 0 if fused else 1)
+        try:
+            m = DINOv2Backbone("micro" if R != 224 else "facebook/dinov2-small", lora_r=bb.lora_r, lora_alpha=1.0, target_dim=bb.target_dim or None,
+                               pretrained=False, precision=precision, config=bb)
+            G.load_np_state(m, sd)
+            m = m.to(G.dev()).eval()
+            tap = m._get_engine().set_tap(0, (3, N, bb.hidden), "cuda:0")
+            m(x)
+            G.sync()
+        finally:
+            nat.set_option("no_fused_patch", -1)
         embs[fused] = tap.cpu().numpy().copy()
     e = rel_err(embs[True], embs[False])
     print(f"fused vs explicit patch embed R={R} {precision}: {e:.2e}")

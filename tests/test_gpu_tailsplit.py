@@ -27,10 +27,10 @@ def data(request):
     global M
     M = request.param
     nat.check(nat.lib().dod_reserve_gemm_scratch(64 << 20))
-    # force the split path for every qualifying shape in THIS module only (dod_debug_set_tailsplit; -1 hands the shipped heuristic
+    # force the split path for every qualifying shape in THIS module only (dod_test_set_option("tailsplit"); -1 hands the shipped heuristic
     # back): the rest of the single-process GPU suite -- the parity gates in test_gpu_forward.py -- runs with production defaults
-    nat.lib().dod_debug_set_tailsplit(2)
-    request.addfinalizer(lambda: nat.lib().dod_debug_set_tailsplit(-1))
+    nat.set_option("tailsplit", 2)
+    request.addfinalizer(lambda: nat.set_option("tailsplit", -1))
     A, W = _n(f"ts.A.{M}", (M, K)), _n("ts.W", (N, K), 0.05)
     bias, scale, resid = _n("ts.b", (N,)), 1 + _n("ts.s", (N,), 0.1), _n(f"ts.r.{M}", (M, N))
     dev = {"bias": bias.cuda(), "scale": scale.cuda()}        # device copies that outlive every launch below
@@ -38,7 +38,7 @@ def data(request):
 
 
 def _took_split(before):
-    return nat.lib().dod_debug_tail_splits() > before
+    return nat.lib().dod_test_counter(b"tail_splits") > before
 
 
 def _rows():
@@ -48,7 +48,7 @@ def _rows():
 def test_tail_split_plain_bf16(data):
     A, W, bias, scale, resid, exact, dev = data
     L = nat.lib()
-    n0 = L.dod_debug_tail_splits()
+    n0 = L.dod_test_counter(b"tail_splits")
     Ab, Wb = A.cuda().bfloat16(), W.cuda().bfloat16()
     ref = Ab.double().cpu() @ Wb.double().cpu().t()
     x = resid.cuda().clone()
@@ -64,7 +64,7 @@ def test_tail_split_plain_bf16(data):
 def test_tail_split_x3(data):
     A, W, bias, scale, resid, exact, dev = data
     L = nat.lib()
-    n0 = L.dod_debug_tail_splits()
+    n0 = L.dod_test_counter(b"tail_splits")
     A2, W2 = _pair(A.cuda()), _pair(W.cuda())
     x = resid.cuda().clone()
     nat.check(L.dod_op_linear_x3(nat.ptr(A2), nat.ptr(W2), M, N, K, nat.ptr(dev["bias"]), nat.ptr(dev["scale"]), nat.ptr(x), N, nat.ptr(x), 0, N, 0, nat.stream_ptr()))
@@ -80,7 +80,7 @@ def test_tail_split_x3(data):
 def test_tail_split_h2(data):
     A, W, bias, scale, resid, exact, dev = data
     L = nat.lib()
-    n0 = L.dod_debug_tail_splits()
+    n0 = L.dod_test_counter(b"tail_splits")
     Ab, _ = pack_h2(A.cuda())
     Wb, wexp = pack_h2(W.cuda(), weight=True)
     x = resid.cuda().clone()

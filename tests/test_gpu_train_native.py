@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from dinov2_od_amd import synth
+from dinov2_od_amd import _native as nat, synth
 from tests import cases
 from tests.cases import rel_err
 
@@ -90,11 +90,11 @@ def test_native_decoder_backward_matches_composite_autograd(case):
     # the unused reference_points head (detr_decoder.py:44-45) gets no gradient in either path
     assert not any(k.startswith("reference_points.") for k in g1)
     if B > 1:       # self-attention adjoint in passes of one image (score scratch capped): same forward bit for bit, same gradients
-        os.environ["DINODET_MHA_CHUNK_IMAGES"] = "1"
+        nat.set_option("mha_chunk_images", 1)
         try:
             l2, b2, dx2, g2 = _run(m, mem, wl, wb, native=True)
         finally:
-            os.environ.pop("DINODET_MHA_CHUNK_IMAGES", None)
+            nat.set_option("mha_chunk_images", -1)
         assert torch.equal(l2, l1) and torch.equal(b2, b1)
         for k in g1:        # weight gradients accumulate atomically: equal up to the order of fp32 additions (a bias gradient is a sum of
             assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-5, k     # B*Q terms of both signs: 2.4e-6 seen on one box, 1e-6 typical)
@@ -114,11 +114,11 @@ def test_native_decoder_dropout_masks_are_consistent_and_seeded():
     c = nt.decoder_train(m, mem, seed=99).detach().clone()
     assert torch.equal(a, b) and not torch.equal(a, c)
     # the self-attention runs in passes over image chunks (score scratch capped): the chunking must change nothing, masks included
-    os.environ["DINODET_MHA_CHUNK_IMAGES"] = "3"         # B = 4: passes of 3 + 1 images
+    nat.set_option("mha_chunk_images", 3)               # B = 4: passes of 3 + 1 images
     try:
         a3 = nt.decoder_train(m, mem, seed=1234).detach().clone()
     finally:
-        os.environ.pop("DINODET_MHA_CHUNK_IMAGES", None)
+        nat.set_option("mha_chunk_images", -1)
     assert torch.equal(a, a3)
     m.eval()                                             # p = 0 through the same entry
     d = nt.decoder_train(m, mem, seed=1234).detach().clone()

@@ -34,6 +34,32 @@ def test_header_symbols_all_exported(lib):
     assert b"gfx950" in lib.dod_version()
 
 
+def test_release_library_has_no_tuning_code(lib):
+    """The release library carries no tuning hooks: none of the dod_debug_* entry points of include/dinodet_tuning.h (in-kernel time
+    stamps, MFMA probes) is exported, and the only DINODET_* environment variables it reads are the operational ones INTEGRATION.md
+    lists (<= 8) -- no variable can make a shipped kernel skip work or pick another tile."""
+    tun = open(os.path.join(ROOT, "include", "dinodet_tuning.h")).read()
+    names = set(re.findall(r"\b(dod_debug_[a-z0-9_]+)\s*\(", tun))
+    assert len(names) >= 5
+    raw = open(nat.LIB_PATH, "rb").read()
+    for n in names:
+        assert not hasattr(lib, n), n
+    assert b"dod_debug_" not in raw
+    env = set(re.findall(rb"DINODET_[A-Z0-9_]+", raw))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert len(env) <= 8, env
+    for v in env:
+        assert v.decode() in doc, f"{v.decode()} is read by the library but not documented in INTEGRATION.md"
+    for gone in (b"DINODET_GEMM_ABL", b"DINODET_DEBUG_NOOUT", b"DINODET_DEBUG_LDA0", b"DINODET_GEMM_TILE", b"DINODET_EPI_RB"):
+        assert gone not in raw
+
+
+def test_test_options_validate_names(lib):
+    assert lib.dod_test_set_option(b"tailsplit", -1) == 0
+    assert lib.dod_test_set_option(b"no_such_option", 1) == 1 and b"unknown" in lib.dod_last_error(None)
+    assert lib.dod_test_counter(b"tail_splits") >= 0 and lib.dod_test_counter(b"nope") == -1
+
+
 def test_config_struct_layout_matches_header():
     hdr = open(os.path.join(ROOT, "include", "dinodet.h")).read()
     body = re.search(r"typedef struct dod_config \{(.*?)\} dod_config;", hdr, re.S).group(1)

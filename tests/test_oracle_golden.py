@@ -110,11 +110,15 @@ def test_oracle_full_depth_vs_reference(variant):
 def test_spatial_factor_quirk():
     """(h,w) includes the CLS token: deformable_attention.py:241-256."""
     from dinov2_od_amd.config import spatial_factor
-    assert spatial_factor(257) == (1, 257)
-    assert spatial_factor(1370) == (10, 137)
-    assert spatial_factor(26) == (2, 13)
-    assert spatial_factor(17) == (1, 17)
-    assert spatial_factor(256) == (16, 16)
+    from oracle.dinodet_oracle import spatial_factor as oracle_factor      # the oracle's own restatement (it imports none of the product's arithmetic)
+    for f in (spatial_factor, oracle_factor):
+        assert f(257) == (1, 257)
+        assert f(1370) == (10, 137)
+        assert f(26) == (2, 13)
+        assert f(17) == (1, 17)
+        assert f(256) == (16, 16)
+    for n in range(1, 3000):                      # host mirror == oracle on every token count a 14-pixel patch grid up to 756 x 756 can produce
+        assert spatial_factor(n) == oracle_factor(n), n
 
 
 def test_bicubic_restatement_matches_torch():

@@ -2,6 +2,7 @@
 """Per-workgroup cycle split of the bf16 attention kernel: tile loop total vs time waiting for K/V DMA + barrier."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._tuning_lib  # noqa: F401,E402  (the -DDINODET_TUNING build: this tool uses tuning hooks)
 import torch, numpy as np
 from dinov2_od_amd import _native as nat
 L = nat.lib(); dev = torch.device("cuda:0")

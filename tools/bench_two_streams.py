@@ -4,6 +4,7 @@ hipGraph, against the single 64-image forward -- does the other half's work fill
     DINODET_GEMM_TAILSPLIT=0 python tools/bench_two_streams.py [precision]      (the tail-split scratch is one buffer per device)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._tuning_lib  # noqa: F401,E402  (the -DDINODET_TUNING build: this tool uses tuning hooks)
 os.environ.setdefault("DINODET_GEMM_TAILSPLIT", "0")
 import torch
 from bench import build, make_images

@@ -3,6 +3,7 @@
 block shapes, interleaved rounds in one process; checks the variants agree (GPU box only)."""
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._tuning_lib  # noqa: F401,E402  (the -DDINODET_TUNING build: this tool uses tuning hooks)
 import torch
 from dinov2_od_amd import _native as nat
 L = nat.lib(); L.dod_reserve_gemm_scratch(64 << 20); dev = torch.device("cuda:0")

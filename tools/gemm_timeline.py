@@ -2,6 +2,7 @@
 """Per-workgroup timeline of the 256x128 GEMM (s_memrealtime stamps, 100 MHz): prologue+loop vs epilogue durations."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._tuning_lib  # noqa: F401,E402  (the -DDINODET_TUNING build: this tool uses tuning hooks)
 import torch, numpy as np
 from dinov2_od_amd import _native as nat
 L = nat.lib(); dev = torch.device("cuda:0")

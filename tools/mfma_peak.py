@@ -3,6 +3,7 @@
 context for the roofline fractions in DESIGN.md (the 2.5 PFLOP/s denominator assumes the 2.4 GHz peak clock)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._tuning_lib  # noqa: F401,E402  (the -DDINODET_TUNING build: this tool uses tuning hooks)
 import torch
 from dinov2_od_amd import _native as nat
 

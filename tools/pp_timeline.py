@@ -3,6 +3,7 @@
     X3=1 python tools/pp_timeline.py        # split-product kernel (DINODET_X3_TILE=p) ; X3=0: plain bf16 (DINODET_GEMM_TILE=q)"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._tuning_lib  # noqa: F401,E402  (the -DDINODET_TUNING build: this tool uses tuning hooks)
 import torch, numpy as np
 from dinov2_od_amd import _native as nat
 L = nat.lib(); L.dod_reserve_gemm_scratch(64 << 20); dev = torch.device("cuda:0")

@@ -7,6 +7,7 @@ v_mfma_f32_32x32x2_f32 probe (one dependent chain per wave, as gemm_f32_kernel i
 prints the two rates."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._tuning_lib  # noqa: F401,E402  (the -DDINODET_TUNING build: this tool uses tuning hooks)
 import torch
 from dinov2_od_amd import _native as nat
 L = nat.lib(); dev = torch.device("cuda:0")
