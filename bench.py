@@ -197,6 +197,40 @@ def oracle_error(gpu_det, oracle_out, C):
             "pred_boxes_rel_l2": l2(g[:n, :, C:], oracle_out["pred_boxes"][:n])}
 
 
+# gate of a rank's detections against the CPU oracle (max-relative, tests/cases.py::rel_err): the parity gate for the gated modes; the
+# throughput modes' own bound (bf16 logits < 8e-2, boxes < 3e-2; fp8 looser) -- a broken rank is off by O(1)
+RANK_GATE = {"fp32": (1e-3, 1e-3), "bf16x3": (1e-3, 1e-3), "fp16x2": (1e-3, 1e-3), "bf16": (8e-2, 3e-2), "fp8": (5e-1, 1e-1)}
+
+
+def rank_oracle_check(st, lo, bb, dc, R, precision, world, device, cpu, stub=None):
+    """N > 1: EVERY rank checks image 0 of its own shard (global image `lo`) of the timed output against the CPU oracle evaluated on its
+    host cores; the errors are all-gathered, rank 0 reports them and the job exits non-zero when any rank leaves its gate."""
+    import torch
+    dist = torch.distributed
+    det = st.last_det[:1].float().cpu() if st.last_det is not None else None
+    if cpu:
+        want = _StubModel(stub.Q, stub.C).forward_packed(st.x[:1]).float()      # a clean evaluation, not the rank's own
+        C = want.shape[-1] - 4
+        e = [float((det[..., :C] - want[..., :C]).abs().max() / want[..., :C].abs().max()), float((det[..., C:] - want[..., C:]).abs().max() / want[..., C:].abs().max())]
+        gate = (1e-6, 1e-6)
+    else:
+        from oracle import dinodet_oracle as orc
+        from dinov2_od_amd import synth
+        torch.set_num_threads(max(1, host_cores() // max(1, world)))
+        sd = {k: torch.from_numpy(v) for k, v in synth.detector_state_dict(bb, dc, seed=1).items()}
+        img = torch.from_numpy(synth.uniform01(0, f"pixel_values.{R}x{R}.{lo}", (3, R, R)))[None]
+        o = orc.detector_forward(sd, bb, dc, img)
+        oe = oracle_error(det.to(device), o, dc.num_classes)
+        e = [oe["pred_logits_max_rel"], oe["pred_boxes_max_rel"]]
+        gate = RANK_GATE[precision]
+    mine = torch.tensor(e, device=device, dtype=torch.float64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    rows = [{"rank": r, "global_image": None, "pred_logits_max_rel": float(v[0]), "pred_boxes_max_rel": float(v[1]),
+             "in_gate": bool(float(v[0]) < gate[0] and float(v[1]) < gate[1])} for r, v in enumerate(allr)]
+    return {"gate_logits_boxes": list(gate), "ranks": rows, "all_in_gate": all(r["in_gate"] for r in rows)}
+
+
 def make_images(B_local, R, lo, device):
     """image g of the global batch (every image distinct: data-dependent clocks), resident on `device`"""
     import torch
@@ -210,12 +244,12 @@ def make_images(B_local, R, lo, device):
 class _StubModel:
     """--rehearse-cpu: stands for the detector; cheap, deterministic per image (so the gather can be checked)"""
 
-    def __init__(self, Q, C):
-        self.Q, self.C = Q, C
+    def __init__(self, Q, C, offset=0.0):
+        self.Q, self.C, self.offset = Q, C, offset      # offset != 0: a rank whose detections are wrong (tests the per-rank gate)
 
     def forward_packed(self, x):
         import torch
-        s = x.flatten(1).mean(dim=1)
+        s = x.flatten(1).mean(dim=1) + self.offset
         return s[:, None, None] + torch.arange(self.Q * (self.C + 4), dtype=torch.float32).view(1, self.Q, self.C + 4)
 
 
@@ -331,11 +365,17 @@ def timed(stepper, steps, warmup, world, device, cpu=False):
         stepper.sync()
         dt = time.perf_counter() - t0
     step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps)) if evs else [1e3 * dt / steps] * steps
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
+    if world > 1:
+        # every rank's own clock around the same K steps + its median step from the event pairs (the spread says whether one GPU or one xGMI
+        # link drags the job); `dt` of the job = MAX over ranks
+        mine = torch.tensor([dt, pct(0.50)], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        timed.per_rank = [{"rank": r, "ms_per_step": 1e3 * float(v[0]) / steps, "step_ms_p50": float(v[1])} for r, v in enumerate(allr)]
+        dt = max(float(v[0]) for v in allr)
+    else:
+        timed.per_rank = None
     return dt, [pct(0.10), pct(0.50), pct(0.90)]
 
 
@@ -432,7 +472,7 @@ def worker(a):
         desc += f" [per-GPU batch overridden to {B_local}]"
     if cpu:
         R, C = 28, 91
-        model, bb, dc = _StubModel(Q, C), None, None
+        model, bb, dc = _StubModel(Q, C, 1.0 if os.environ.get("BENCH_REHEARSE_BREAK_RANK") == str(rank) else 0.0), None, None
     else:
         model, bb, dc = build(name, Q, a.precision, device)
         C = dc.num_classes
@@ -444,12 +484,20 @@ def worker(a):
     dt, pcts = timed(st, a.steps, a.warmup, world, device, cpu)
     global_batch = B_local * world
     ips = global_batch * a.steps / dt
+    per_rank = timed.per_rank
     gather_ok = None
+    rank_check = None
     if world > 1:       # the gathered buffer holds every rank's detections in rank order (checked on the last step's buffer)
         g = st.last_gathered()
         with torch.no_grad():
             mine = model.forward_packed(x)
-        gather_ok = bool(torch.allclose(g[lo:hi].cpu(), mine.cpu(), rtol=0, atol=0)) and g.shape[0] == global_batch
+        ok_here = bool(torch.allclose(g[lo:hi].cpu(), mine.cpu(), rtol=0, atol=0)) and g.shape[0] == global_batch
+        flag = torch.tensor([1.0 if ok_here else 0.0], device=device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)      # every rank's view of the gathered buffer, not only rank 0's
+        gather_ok = bool(flag.item() > 0.5)
+        rank_check = rank_oracle_check(st, lo, bb, dc, R, a.precision, world, device, cpu, stub=model if cpu else None)
+        for r_ in rank_check["ranks"]:
+            r_["global_image"] = ddist.shard_bounds(global_batch, r_["rank"], world)[0]
 
     res = {"metric": "images/sec forward, DINOv2 ViT-B/14 518x518 + 100-query head" if a.workload == "vitb518" else f"images/sec forward, {a.workload}",
            "value": ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -462,6 +510,10 @@ def worker(a):
                       "gather_checked": gather_ok,
                       "micro_batches": None if cpu else (lambda e: e.micro_streams if e._micro_ok(B_local, R, R) else 1)(model._get_engine())},
            "step_ms_p10_p50_p90": pcts}
+    if world > 1:
+        ms = [r_["ms_per_step"] for r_ in per_rank]
+        res["per_rank"] = {"ms_per_step": per_rank, "spread_ms": max(ms) - min(ms), "slowest_rank": ms.index(max(ms)),
+                           "gpu_vs_oracle": rank_check}
     if cpu:
         res["metric"] = "REHEARSAL (CPU stub model, gloo): control flow only, not a measurement"
         res["data"] = "rehearsal-cpu"
@@ -558,6 +610,12 @@ def worker(a):
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+        # a rank whose detections left the gate, or a gathered buffer that does not hold every rank's rows, fails the whole job (every
+        # rank exits non-zero: the launcher propagates the first non-zero code)
+        if not gather_ok or not rank_check["all_in_gate"]:
+            if rank == 0:
+                print(f"[bench] FAILED: gather_checked={gather_ok}, per-rank oracle check {rank_check}", file=sys.stderr)
+            sys.exit(3)
 
 
 def main():

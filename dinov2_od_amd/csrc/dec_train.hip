@@ -14,6 +14,7 @@
 // accumulate) -- no transposed copies.  Self-attention (forward and adjoint) is batched GEMMs over (image, head) around one row
 // kernel.  Dropout masks come from a counter-based hash of (seed, site, element): the backward regenerates them, nothing but
 // activations is taped.
+#include <mutex>
 #include "dod_common.h"
 #include "../../include/dinodet.h"
 
@@ -40,6 +41,41 @@ __host__ __device__ inline unsigned long long site_key(unsigned long long seed, 
   return seed * 0xD1342543DE82EF95ull + (unsigned long long)(layer * 8 + site + 1) * 0x9E3779B97F4A7C15ull;
 }
 
+// ------------------------------------------------------------------------------------------------ deterministic mode
+// DINODET_DETERMINISTIC=1 (or the test option "deterministic"): every reduction that the fast step spreads over workgroups and merges with
+// fp32 atomics -- K-split weight / activation gradient products, bias column sums, LayerNorm and LoRA parameter gradients, the scatter of
+// the deformable sampling adjoint and its shared reference-logit columns -- runs in a FIXED order instead: run-to-run bit-identical
+// gradients (the fast step agrees with itself to ~1e-6: r3_t8.log), at roughly twice the step time.
+static bool det_mode() {
+  const int o = dod_option(DOD_OPT_DETERMINISTIC);
+  if (o >= 0) return o != 0;
+  static const bool env = [] { const char* v = getenv("DINODET_DETERMINISTIC"); return v && v[0] == '1'; }();
+  return env;
+}
+// partial-sum scratch of the ordered reductions (per device, grown on demand; the training step is never stream-captured)
+static float* det_scratch(size_t floats) {
+  static std::mutex mu;
+  static float* buf[16] = {};
+  static size_t cap[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (cap[dev] < floats) {
+    if (buf[dev]) { (void)hipDeviceSynchronize(); (void)hipFree(buf[dev]); buf[dev] = nullptr; cap[dev] = 0; }
+    if (hipMalloc((void**)&buf[dev], floats * 4) != hipSuccess) return nullptr;
+    cap[dev] = floats;
+  }
+  return buf[dev];
+}
+// dst[c] += part[0][c] + part[1][c] + ... in that order (part: [nparts][cols])
+__global__ void ordered_add_kernel(const float* __restrict__ part, int nparts, int stride, int cols, float* __restrict__ dst) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float acc = 0.f;
+  for (int i = 0; i < nparts; ++i) acc += part[(size_t)i * stride + c];
+  dst[c] += acc;
+}
+
 // ------------------------------------------------------------------------------------------------ small kernels
 // dst[c] += sum_r src[r][c]
 __global__ void colsum_kernel(const float* __restrict__ src, int ld, int rows, int cols, float* __restrict__ dst) {
@@ -55,6 +91,7 @@ __global__ void colsum_kernel(const float* __restrict__ src, int ld, int rows, i
 }
 int colsum_add(const float* src, int ld, int rows, int cols, float* dst, hipStream_t s) {
   int gy = (rows + 63) / 64; gy = gy < 1 ? 1 : (gy > 128 ? 128 : gy);
+  if (det_mode()) gy = 1;      // one workgroup per 64 columns walks every row: a single adder per column
   hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, gy), dim3(256), 0, s, src, ld, rows, cols, dst);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
@@ -151,7 +188,7 @@ __global__ void batch_sum_kernel(const float* __restrict__ d, float* __restrict_
 template <int MAXC>       // 64-column chunks per lane: 16 (D <= 1024) or 32 (D <= 2048: ViT-g's 1536)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dy,
                                                      float eps, int rows, int D, float* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta) {
+                                                     float* __restrict__ dbeta, float* __restrict__ part) {
   const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   float dg[MAXC], db[MAXC];
 #pragma unroll
@@ -192,15 +229,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   for (int c = 0; c < MAXC; ++c) { sg[w][c * 64 + lane] = dg[c]; sb[w][c * 64 + lane] = db[c]; }
   __syncthreads();
   for (int k = threadIdx.x; k < D; k += 256) {
-    atomicAdd(dgamma + k, (sg[0][k] + sg[1][k]) + (sg[2][k] + sg[3][k]));
-    atomicAdd(dbeta + k, (sb[0][k] + sb[1][k]) + (sb[2][k] + sb[3][k]));
+    const float g_ = (sg[0][k] + sg[1][k]) + (sg[2][k] + sg[3][k]), b_ = (sb[0][k] + sb[1][k]) + (sb[2][k] + sb[3][k]);
+    if (part) { part[((size_t)blockIdx.x * 2) * D + k] = g_; part[((size_t)blockIdx.x * 2 + 1) * D + k] = b_; }      // deterministic mode: merged in block order
+    else { atomicAdd(dgamma + k, g_); atomicAdd(dbeta + k, b_); }
   }
 }
 int ln_bwd(const float* x, const float* gamma, const float* dy, float eps, int rows, int D, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
   if (D > 2048) return 2;
   int blocks = (rows + 3) / 4; blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);      // one row per wave up to 8 192 rows
-  if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, x, gamma, dy, eps, rows, D, dx, dgamma, dbeta);
-  else hipLaunchKernelGGL(ln_bwd_kernel<32>, dim3(blocks), dim3(256), 0, s, x, gamma, dy, eps, rows, D, dx, dgamma, dbeta);
+  float* part = nullptr;
+  if (det_mode()) {
+    blocks = blocks > 256 ? 256 : blocks;
+    part = det_scratch((size_t)blocks * 2 * D);
+    if (!part) return 3;
+  }
+  if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, x, gamma, dy, eps, rows, D, dx, dgamma, dbeta, part);
+  else hipLaunchKernelGGL(ln_bwd_kernel<32>, dim3(blocks), dim3(256), 0, s, x, gamma, dy, eps, rows, D, dx, dgamma, dbeta, part);
+  if (part) {      // part rows alternate (dgamma, dbeta) per block: two strided ordered sums
+    hipLaunchKernelGGL(ordered_add_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part, blocks, 2 * D, D, dgamma);
+    hipLaunchKernelGGL(ordered_add_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part + D, blocks, 2 * D, D, dbeta);
+  }
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -382,9 +430,12 @@ static int launch_mha_bwd(const float* qkv, int ld, const float* dO, int ldo, fl
 // ------------------------------------------------------------------------------------------------ deformable gather backward
 // Adjoint of deform_sample_kernel (deform.hip; deformable_attention.py:101-174).  One wave per (b, q, head), lanes along dh.
 // dproj must be zero on entry (the two reference-logit columns are shared by all heads: float atomics); dvalues accumulates.
+// DET (deterministic mode): no scatter and no atomics here -- the value gradient comes from deform_bwd_values_det_kernel (a gather in a
+// fixed order), the heads' contributions to the two shared reference-logit columns go to dref_part [B*Q*Hd][2] and are summed head by head.
+template <bool DET>
 __global__ __launch_bounds__(256) void deform_bwd_kernel(const float* __restrict__ proj, int ldp, const float* __restrict__ values,
                                                          const float* __restrict__ dout, int B, int Q, int N, int Hd, int P, int dh, int h,
-                                                         int w, float* __restrict__ dproj, float* __restrict__ dvalues) {
+                                                         int w, float* __restrict__ dproj, float* __restrict__ dvalues, float* __restrict__ dref_part) {
   const int lane = threadIdx.x & 63;
   const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= (long)B * Q * Hd) return;
@@ -433,11 +484,11 @@ __global__ __launch_bounds__(256) void deform_bwd_kernel(const float* __restrict
       const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;
       da[p] = p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11;      // d out / d a_p
       // corner scatter: dV_c += a w_c g
-      if (d0ok) {
+      if (!DET && d0ok) {
         atomicAdd(dvb + i00 + lane, a * w00 * g0); atomicAdd(dvb + i01 + lane, a * w01 * g0);
         atomicAdd(dvb + i10 + lane, a * w10 * g0); atomicAdd(dvb + i11 + lane, a * w11 * g0);
       }
-      if (d1ok) {
+      if (!DET && d1ok) {
         atomicAdd(dvb + i00 + lane + 64, a * w00 * g1); atomicAdd(dvb + i01 + lane + 64, a * w01 * g1);
         atomicAdd(dvb + i10 + lane + 64, a * w10 * g1); atomicAdd(dvb + i11 + lane + 64, a * w11 * g1);
       }
@@ -458,9 +509,82 @@ __global__ __launch_bounds__(256) void deform_bwd_kernel(const float* __restrict
   if (lane == 0) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) if (p < P) dpr[2 + Hd * P * 2 + hd * P + p] = (aw[p] / den) * (da[p] - dotp);
-    atomicAdd(dpr + 0, drefx * refx * (1.0f - refx));        // sigmoid of the reference logits
-    atomicAdd(dpr + 1, drefy * refy * (1.0f - refy));
+    if (DET) {
+      dref_part[item * 2] = drefx * refx * (1.0f - refx);
+      dref_part[item * 2 + 1] = drefy * refy * (1.0f - refy);
+    } else {
+      atomicAdd(dpr + 0, drefx * refx * (1.0f - refx));        // sigmoid of the reference logits
+      atomicAdd(dpr + 1, drefy * refy * (1.0f - refy));
+    }
   }
+}
+// deterministic mode: dproj[bq][0..1] = sum over heads, in head order, of dref_part
+__global__ void deform_dref_det_kernel(const float* __restrict__ dref_part, int BQ, int Hd, int ldp, float* __restrict__ dproj) {
+  const int bq = blockIdx.x * 256 + threadIdx.x;
+  if (bq >= BQ) return;
+  float ax = 0.f, ay = 0.f;
+  for (int hd = 0; hd < Hd; ++hd) { ax += dref_part[((size_t)bq * Hd + hd) * 2]; ay += dref_part[((size_t)bq * Hd + hd) * 2 + 1]; }
+  dproj[(size_t)bq * ldp] += ax;
+  dproj[(size_t)bq * ldp + 1] += ay;
+}
+// deterministic mode: the adjoint of the bilinear gather as a GATHER -- one wave per (image, token, head) walks the image's Q x P samples
+// in order (lanes along the samples: each recomputes its sample's corners as deform_bwd_kernel does and keeps its weight on THIS token),
+// then adds the matching samples' a w g rows in ascending (q, p) order.  One writer per dvalues row: no atomics, a fixed order.
+__global__ __launch_bounds__(256) void deform_bwd_values_det_kernel(const float* __restrict__ proj, int ldp, const float* __restrict__ dout, int B, int Q, int N,
+                                                                    int Hd, int P, int dh, int h, int w, float* __restrict__ dvalues) {
+  const int lane = threadIdx.x & 63;
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (long)B * N * Hd) return;
+  const int hd = (int)(item % Hd);
+  const long bn = item / Hd;
+  const int b = (int)(bn / N), n = (int)(bn % N);
+  const int Dd = Hd * dh, QP = Q * P;
+  float acc0 = 0.f, acc1 = 0.f;
+  for (int s0 = 0; s0 < QP; s0 += 64) {
+    const int sidx = s0 + lane;
+    float wt = 0.f;
+    if (sidx < QP) {
+      const int q = sidx / P, p = sidx - q * P;
+      const float* pr = proj + ((size_t)b * Q + q) * ldp;
+      const float refx = sigmoidf_(pr[0]), refy = sigmoidf_(pr[1]);
+      const float* awl = pr + 2 + Hd * P * 2 + hd * P;
+      float mx = -INFINITY;
+      for (int pp = 0; pp < P; ++pp) mx = fmaxf(mx, awl[pp]);
+      float den = 0.f;                                            // the same 8-slot sum as deform_bwd_kernel
+#pragma unroll
+      for (int pp = 0; pp < 8; ++pp) den += pp < P ? expf(awl[pp] - mx) : 0.f;
+      const float a = expf(awl[p] - mx) / den;
+      const float* off = pr + 2 + hd * P * 2;
+      const float sx = refx + off[2 * p], sy = refy + off[2 * p + 1];
+      float lx = fminf(fmaxf(sx, 0.f), 1.f), ly = fminf(fmaxf(sy, 0.f), 1.f);
+      lx = lx * (float)(w - 1);
+      ly = ly * (float)(h - 1);
+      int x0 = (int)floorf(lx), y0 = (int)floorf(ly);
+      int x1 = x0 + 1, y1 = y0 + 1;
+      x0 = min(max(x0, 0), w - 1); x1 = min(max(x1, 0), w - 1);
+      y0 = min(max(y0, 0), h - 1); y1 = min(max(y1, 0), h - 1);
+      const float wx1 = lx - (float)x0, wx0 = 1.0f - wx1;
+      const float wy1 = ly - (float)y0, wy0 = 1.0f - wy1;
+      // corners in the scatter kernel's order 00, 01, 10, 11 (clamped corners may coincide: their weights add, as their atomics did)
+      if (y0 * w + x0 == n) wt += a * (wx0 * wy0);
+      if (y1 * w + x0 == n) wt += a * (wx0 * wy1);
+      if (y0 * w + x1 == n) wt += a * (wx1 * wy0);
+      if (y1 * w + x1 == n) wt += a * (wx1 * wy1);
+    }
+    unsigned long long hit = __ballot(wt != 0.f);
+    while (hit) {
+      const int l = __ffsll((long long)hit) - 1;
+      hit &= hit - 1;
+      const float wl = __shfl(wt, l, 64);
+      const int q = (s0 + l) / P;
+      const float* g = dout + ((size_t)b * Q + q) * Dd + hd * dh;
+      if (lane < dh) acc0 = fmaf(wl, g[lane], acc0);
+      if (lane + 64 < dh) acc1 = fmaf(wl, g[lane + 64], acc1);
+    }
+  }
+  float* dv = dvalues + ((size_t)b * N + n) * Dd + hd * dh;
+  if (lane < dh) dv[lane] += acc0;
+  if (lane + 64 < dh) dv[lane + 64] += acc1;
 }
 
 // ------------------------------------------------------------------------------------------------ orchestration
@@ -541,6 +665,7 @@ GemmF32X xgemm(const float* A, int lda, bool a_km, const float* W, int ldw, bool
 // K slices for a product whose 64x64 tiles leave most of the chip idle (the decoder's 1 600-row linears: 300 tiles, a lone
 // workgroup's 16-k tile takes ~1 us): target ~768 workgroups of at least 8 k-tiles each; 1 = do not split
 int ksplit_for(int rows, int cols, int K) {
+  if (det_mode()) return 1;      // one workgroup owns an output tile: no atomic merge of K slices
   static const int target = [] { const char* e = DOD_TUNE_ENV("DINODET_F32_KSPLIT_WGS"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
   const int tiles = ((rows + 63) / 64) * ((cols + 63) / 64), nkt = (K + 15) / 16;
   if (tiles >= target) return 1;
@@ -711,8 +836,18 @@ int dod_decoder_train_backward(const dod_config* cfg, const dod_dec_train_params
     TK(lin_bwd_w(sc.dbr, Dd, L.samp, Dd, BQ, Dd, Dd, G(grads->op_w), G(grads->op_b), s));
     TK(lin_bwd_x(sc.dbr, Dd, p->op_w, BQ, Dd, Dd, sc.dt, false, s));                                   // dt = d(samp)
     TH(hipMemsetAsync(sc.dproj, 0, (size_t)BQ * d.ncp * 4, s));
-    hipLaunchKernelGGL(deform_bwd_kernel, dim3((unsigned)(((long)BQ * d.Hd + 3) / 4)), dim3(256), 0, s, L.proj, d.ncp, t.values, sc.dt, B, Q, N, d.Hd, d.P,
-                       d.dh, d.fh, d.fw, sc.dproj, sc.dvalues);
+    if (det_mode()) {
+      float* dref_part = det_scratch((size_t)BQ * d.Hd * 2);
+      if (!dref_part) return tfail(DOD_ERR_HIP, "deterministic mode: scratch allocation failed");
+      hipLaunchKernelGGL(deform_bwd_kernel<true>, dim3((unsigned)(((long)BQ * d.Hd + 3) / 4)), dim3(256), 0, s, L.proj, d.ncp, t.values, sc.dt, B, Q, N, d.Hd,
+                         d.P, d.dh, d.fh, d.fw, sc.dproj, sc.dvalues, dref_part);
+      hipLaunchKernelGGL(deform_dref_det_kernel, dim3((BQ + 255) / 256), dim3(256), 0, s, dref_part, BQ, d.Hd, d.ncp, sc.dproj);
+      hipLaunchKernelGGL(deform_bwd_values_det_kernel, dim3((unsigned)(((long)B * N * d.Hd + 3) / 4)), dim3(256), 0, s, L.proj, d.ncp, sc.dt, B, Q, N, d.Hd,
+                         d.P, d.dh, d.fh, d.fw, sc.dvalues);
+    } else {
+      hipLaunchKernelGGL(deform_bwd_kernel<false>, dim3((unsigned)(((long)BQ * d.Hd + 3) / 4)), dim3(256), 0, s, L.proj, d.ncp, t.values, sc.dt, B, Q, N, d.Hd,
+                         d.P, d.dh, d.fh, d.fw, sc.dproj, sc.dvalues, nullptr);
+    }
     TH(hipGetLastError());
     TK(lin_bwd_w(sc.dproj, d.ncp, L.tgt1, Dd, BQ, d.ncat, Dd, sc.dcat_w, sc.dcat_b, s));
     TK(lin_bwd_x(sc.dproj, d.ncp, sc.cat_w, BQ, d.ncat, Dd, sc.dtgt, true, s));                        // dtgt = d(tgt1)
@@ -1047,23 +1182,28 @@ __global__ __launch_bounds__(256) void lora_up_kernel(const float* __restrict__ 
                                                       float* __restrict__ G, int sg_o, int sg_c) {
   __shared__ float sT[LORA_UP_ROWS][LORA_RMAX];
   const int o = blockIdx.x * 256 + threadIdx.x;
-  const int m0 = blockIdx.y * LORA_UP_ROWS;
-  const int nm = M - m0 < LORA_UP_ROWS ? M - m0 : LORA_UP_ROWS;
-  for (int i = threadIdx.x; i < LORA_UP_ROWS * LORA_RMAX; i += 256) {
-    const int mm = i / LORA_RMAX, c = i % LORA_RMAX;
-    sT[mm][c] = (mm < nm && c < r) ? T[(size_t)(m0 + mm) * ldt + c] : 0.f;
-  }
-  __syncthreads();
-  if (o >= O) return;
   float acc[LORA_RMAX];
 #pragma unroll
   for (int c = 0; c < LORA_RMAX; ++c) acc[c] = 0.f;
-  const float* y = Y + (size_t)m0 * ldy + o;
-  for (int mm = 0; mm < nm; ++mm) {
-    const float yv = y[(size_t)mm * ldy];
+  // a workgroup walks the row chunks blockIdx.y, blockIdx.y + gridDim.y, ...: gridDim.y = 1 (deterministic mode) makes it the only adder
+  for (int m0 = blockIdx.y * LORA_UP_ROWS; m0 < M; m0 += gridDim.y * LORA_UP_ROWS) {
+    const int nm = M - m0 < LORA_UP_ROWS ? M - m0 : LORA_UP_ROWS;
+    __syncthreads();
+    for (int i = threadIdx.x; i < LORA_UP_ROWS * LORA_RMAX; i += 256) {
+      const int mm = i / LORA_RMAX, c = i % LORA_RMAX;
+      sT[mm][c] = (mm < nm && c < r) ? T[(size_t)(m0 + mm) * ldt + c] : 0.f;
+    }
+    __syncthreads();
+    if (o < O) {
+      const float* y = Y + (size_t)m0 * ldy + o;
+      for (int mm = 0; mm < nm; ++mm) {
+        const float yv = y[(size_t)mm * ldy];
 #pragma unroll
-    for (int c = 0; c < LORA_RMAX; ++c) acc[c] = fmaf(yv, sT[mm][c], acc[c]);
+        for (int c = 0; c < LORA_RMAX; ++c) acc[c] = fmaf(yv, sT[mm][c], acc[c]);
+      }
+    }
   }
+  if (o >= O) return;
 #pragma unroll
   for (int c = 0; c < LORA_RMAX; ++c)
     if (c < r) unsafeAtomicAdd(G + (size_t)o * sg_o + (size_t)c * sg_c, acc[c]);
@@ -1073,7 +1213,7 @@ int lora_down(const float* X, int ldx, const float* A, int sa_c, int sa_k, int M
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 int lora_up(const float* Y, int ldy, const float* T, int ldt, int M, int O, int r, float* G, int sg_o, int sg_c, hipStream_t s) {
-  hipLaunchKernelGGL(lora_up_kernel, dim3((O + 255) / 256, (M + LORA_UP_ROWS - 1) / LORA_UP_ROWS), dim3(256), 0, s, Y, ldy, T, ldt, M, O, r, G, sg_o, sg_c);
+  hipLaunchKernelGGL(lora_up_kernel, dim3((O + 255) / 256, det_mode() ? 1 : (M + LORA_UP_ROWS - 1) / LORA_UP_ROWS), dim3(256), 0, s, Y, ldy, T, ldt, M, O, r, G, sg_o, sg_c);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

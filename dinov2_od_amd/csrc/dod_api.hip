@@ -314,7 +314,7 @@ int finalize_impl(dod_handle* h, hipStream_t s) {
     // norm1 / norm2 folded into the QKV / MLP-in GEMMs (bf16 and the compensated modes; the strict fp32 and the fp8 schedule keep the LayerNorm
     // kernel): W' = W diag(gamma), b' = b + W beta, c = row sums of what the MFMAs multiply.  DINODET_LN_FOLD=0 (or the test option): the
     // round-3 schedule.
-    static const bool fold_env = [] { const char* v = getenv("DINODET_LN_FOLD"); return v && v[0] == '1'; }();      // (off until it pays: r4_exp1)
+    static const bool fold_env = [] { const char* v = getenv("DINODET_LN_FOLD"); return !(v && v[0] == '0'); }();
     const int fold_opt = dod_option(DOD_OPT_LN_FOLD);
     L.fold = (fold_opt >= 0 ? fold_opt != 0 : fold_env) && !f8 && (is_bf16(h) || is_x3(h)) && D % 32 == 0;
     auto fold_ln = [&](const float* w, int rows, const float* gamma, const float* beta, float* bias) -> float* {      // -> folded fp32 copy (temporary)
@@ -637,7 +637,7 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   const int op_kind = is_h2(h) ? LNOP_H2 : (x3 ? LNOP_PAIR : LNOP_BF16);
   const int npart = (D + 127) / 128;
   auto ln_producer = [&](GemmEpi e, bool wanted) {      // residual epilogue: + operand copy of the new rows + their group statistics
-    if (fold && wanted) { e.ln_op = ws.y; e.ln_op_kind = op_kind; e.ln_op_ld = (op_kind == LNOP_BF16 ? D : 2 * D); e.ln_part = ws.lnp; e.ln_npart = npart; }
+    if (fold && wanted) { e.ln_op = ws.y; e.ln_op_kind = op_kind; e.ln_op_ld = (op_kind == LNOP_BF16 ? D : 2 * D); e.ln_part = ws.lnp; e.ln_npart = npart; e.ln_shift = ws.lns; }
     return e;
   };
   auto ln_consumer = [&](GemmEpi e, const float* csum) { if (fold) { e.ln_stats = ws.lns; e.ln_c = csum; } return e; };
@@ -1311,7 +1311,7 @@ int dod_op_linear_ln(int family, const void* A, const void* W, const void* wexp,
   if (out_layout == 3) e.out_h2 = 1;
   e.ln_stats = (const float2*)ln->stats; e.ln_c = ln->csum;
   if (ln->part) {
-    e.ln_part = (float2*)ln->part; e.ln_npart = (N + 127) / 128; e.ln_op = ln->op_out;
+    e.ln_part = (float2*)ln->part; e.ln_npart = (N + 127) / 128; e.ln_op = ln->op_out; e.ln_shift = (const float2*)ln->shift;
     e.ln_op_kind = family == DOD_PREC_FP16X2 ? LNOP_H2 : (family == DOD_PREC_BF16X3 ? LNOP_PAIR : LNOP_BF16);
     e.ln_op_ld = family == DOD_PREC_BF16 ? N : 2 * N;
   }

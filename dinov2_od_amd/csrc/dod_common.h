@@ -169,12 +169,13 @@ struct GemmEpi {
   // c[n] = sum_k W'[n][k] and b' = b + W beta:   LN(x) W^T + b  =  rstd (x W'^T - mean c) + b'  -- the linear reads the residual row x itself
   // (in its operand format) and normalises in its epilogue, so no LayerNorm pass reads the fp32 stream.
   //   producer (the in-place residual epilogue of out-proj / fc2): beside the fp32 row it writes the row in the next GEMM's operand format
-  //   and, per 128-column group g, (sum, centred sum of squares) of the new row to ln_part[m * ln_npart + g] (merged by ln_finalize_kernel);
+  //   and, per 128-column group g, (sum, sum of squares) of the new row minus a per-row shift to ln_part[m * ln_npart + g] (ln_finalize_kernel);
   void* ln_op;            //   operand copy of the new residual rows, or null
   int ln_op_kind;         //   LNOP_BF16 (pitch ln_op_ld bf16) / LNOP_PAIR ([hi | lo], each ln_op_ld / 2 wide) / LNOP_H2 (H2 rows, pitch 2 * ln_op_ld bytes)
   int ln_op_ld;
-  float2* ln_part;
+  float2* ln_part;        //   [M][ln_npart] (sum, sum of squares) of (row - shift) per group
   int ln_npart;           //   = ceil(N / 128)
+  const float2* ln_shift; //   [M]: .x = the shift of row m (its previous mean; null = 0) -- ln_finalize_kernel reads the same value
   //   consumer (QKV, fc1 / weights_in): v = (acc - mean[m] c[n]) rstd[m] before the bias
   const float2* ln_stats; //   [M] (mean, rstd), or null
   const float* ln_c;      //   [N]
@@ -230,7 +231,8 @@ int launch_layernorm(const float* x, const float* add, const float* gamma, const
 // rows of x -> operand copy of x ITSELF (kind LNOP_*, as GemmEpi::ln_op) + (mean, rstd) per row: what the first block's QKV needs (its
 // producer is the patch embedding, not a residual GEMM)
 int launch_rowstats(const float* x, int rows, int D, float eps, void* op, int op_kind, float2* stats, hipStream_t s);
-// (sum, centred square sum) per 128-column group [rows][npart] -> (mean, rstd) [rows]   (Chan's pairwise combination)
+// (sum, sum of squares) of (row - shift) per 128-column group [rows][npart] -> stats[row] = (mean, rstd); IN: stats[row].x = the shift the
+// producer used (GemmEpi::ln_shift pointed here, or zeros)
 int launch_ln_finalize(const float2* part, int npart, int rows, int D, float eps, float2* stats, hipStream_t s);
 // pack time: Wout[n][k] = W[n][k] gamma[k],  bias_out[n] = bias_in[n] + sum_k W[n][k] beta[k]   (Wout may alias W, bias_out bias_in)
 int launch_ln_fold(const float* W, int rows, int cols, const float* gamma, const float* beta, const float* bias_in, float* Wout, float* bias_out, hipStream_t s);

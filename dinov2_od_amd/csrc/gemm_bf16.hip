@@ -27,6 +27,7 @@
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+template <int LN>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int lda,
                                                         const bf16_t* __restrict__ W, int ldw,
                                                         int M, int N, int K, GemmEpi e) {
@@ -128,9 +129,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       stage_acc(smem, PITCH, wm * 64 + i * 32 + lr, wn * 64 + j * 32, acc[i][j], lh);
-  const ColParams cp = load_col_params<BN>(e, n0, N, tid);
+  const ColParams cp = load_col_params<BN, LN>(e, n0, N, tid);
+  auto rowmap = [&](int row_l) { return m0 + row_l; };
+  stage_row_stats<BM, BN, LN>(smem, PITCH, e, M, tid, rowmap);
   __syncthreads();
-  drain_tile<BM, BN, 256>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m0 + row_l; });
+  drain_tile<BM, BN, 256, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);
 }
 
 // (The 256x256 8-wave, 256x256x64, 256x128 32x32x16 and 16-wave 256x256x32 variants of rounds 1-2 -- each measured against the kernels
@@ -169,6 +172,7 @@ __device__ __forceinline__ int swz64m16(int row, int chunk) { return chunk ^ (((
 __device__ unsigned long long* g_gemm_stamps = nullptr;
 #endif
 
+template <int LN>
 __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf16_t* __restrict__ A, int lda,
                                                                        const bf16_t* __restrict__ W, int ldw,
                                                                        int M, int N, int K, GemmEpi e, int GM) {
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
 #endif
   // epilogue: D = W A^T: lane&15 = m within the 16-row block, (lane>>4)*4 + reg = n within the 16-col block
   constexpr int PITCH = B5N * 4 + 16;
-  const ColParams cp = load_col_params<B5N>(e, n0, N, tid);
+  const ColParams cp = load_col_params<B5N, LN>(e, n0, N, tid);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __builtin_amdgcn_s_barrier();
@@ -255,9 +259,10 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
         const f32x4 a = acc[pass * 2 + ii][j];
         *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
       }
+    auto rowmap = [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); };
+    stage_row_stats<128, B5N, LN>(smem, PITCH, e, M, tid, rowmap);
     __syncthreads();
-    drain_tile<128, B5N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                              [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+    drain_tile<128, B5N, 512, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);
   }
 #ifdef DINODET_TUNING
   if (stamps && tid == 0) {
@@ -282,8 +287,10 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_m16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
+#define ATTR_(LN_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<LN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS128); \
+                   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_m16_kernel<LN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
+    ATTR_(LN_NONE) ATTR_(LN_CONS) ATTR_(LN_PROD)
+#undef ATTR_
     attr_set[dev] = true;
   }
   const char* force = DOD_TUNE_ENV("DINODET_GEMM_TILE");     // tuning builds: "q" ping-pong, "x" 16-wave k64, "8" 256x128, "1" 128x128
@@ -296,6 +303,7 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   // grouped-order depth of the 256x128 kernel (m-tiles per group inside an XCD's run), measured: 8 for N = 3072, 4 for 2304, 2 for 768
   const int gm5 = (N >= 3072 ? 8 : (N >= 2048 ? 4 : 2)) | (gemm_tile_mode() & 0x300);
   const int tiles5 = ((M + B5M - 1) / B5M) * ((N + B5N - 1) / B5N);
+#define GO_M16(LN_) hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel<LN_>, dim3(tiles5), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e, gm5);
   if (!force && M >= 4096 && N >= 512 && K % 64 == 0 && e.act != ACT_SIGMOID && e.rows_per_img == 0) {
     // Round-aware choice between the 256x256 tiles (one workgroup per CU: the 16-wave `k64` kernel of gemm_x3.hip -- 256x256x64, two 64-KiB
     // slots: QKV 760 / out-proj 460 / fc2 765 TFLOP/s at M = 87 680 -- or the 8-wave ping-pong kernel of gemm_pp.hip, 3-7 % faster on
@@ -314,7 +322,7 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
       if (N >= 1536) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
       return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
     }
-    hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel, dim3(tiles5), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e, gm5);
+    LN_DISPATCH(e, GO_M16)
     return hipGetLastError() == hipSuccess ? 0 : 3;
   }
   // Below that: 256x128x32 on v_mfma_f32_16x16x32_bf16 (two workgroups per CU) from 1 024 rows up, 128x128 for small M (decoder memory at small
@@ -325,13 +333,16 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   const bool few = (long)tiles5 * 2 <= 256 + 64;
   const bool m16 = force ? (force[0] == '8') : (M >= 1024 && N >= 128 && !few);
   if (m16) {
-    hipLaunchKernelGGL(gemm_bf16_256x128_m16_kernel, dim3(tiles5), dim3(512), LDS5, s, A, lda, W, ldw, M, N, K, e, gm5);
+    LN_DISPATCH(e, GO_M16)
   } else {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles), dim3(256), LDS128, s, A, lda, W, ldw, M, N, K, e);
+#define GO_128(LN_) hipLaunchKernelGGL(gemm_bf16_kernel<LN_>, dim3(tiles), dim3(256), LDS128, s, A, lda, W, ldw, M, N, K, e);
+    LN_DISPATCH(e, GO_128)
+#undef GO_128
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
+#undef GO_M16
 
 #ifdef DINODET_TUNING
 extern "C" int dod_debug_gemm_stamps(void* dev_buf) {

@@ -94,25 +94,61 @@ __device__ __forceinline__ void stage_acc(char* sm, int pitch, int row_l, int co
   }
 }
 
+// LN (compile time; GemmEpi::ln_*): LN_NONE, LN_CONS = the folded-LayerNorm consumer (QKV, fc1 / weights_in), LN_PROD = the producer (the
+// in-place residual epilogue of out-proj / fc2).  A kernel template parameter, so that the kernels without a fold compile exactly as before.
+enum { LN_NONE = 0, LN_CONS = 1, LN_PROD = 2 };
+// Folded LayerNorm: the per-row scalars the drain needs -- (mean, rstd) for the consumer, the shift for the producer -- ride in the 16 bytes of
+// padding behind each row of the staged tile: ONE vector-memory instruction per pass (threads 0..ROWS-1) instead of one per row visit.  The
+// epilogues are paced by their vector-memory INSTRUCTIONS, not their bytes: fetched per visit, the statistics cost the QKV GEMM +42 us and
+// fc1 +32 us (profiles/r04_lnfold_ab.txt).  Call between staging the accumulators and the barrier in front of the drain.
+template <int ROWS, int COLS, int LN, typename RowMap>
+__device__ __forceinline__ void stage_row_stats(char* sm, int pitch, const GemmEpi& e, int M, int tid, RowMap rowmap) {
+  if (LN == LN_NONE) return;
+  if (tid < ROWS) {
+    const float2* src = LN == LN_CONS ? e.ln_stats : e.ln_shift;
+    const int m = rowmap(tid);
+    float2 st = make_float2(0.f, 0.f);
+    if (src && m < M) st = src[m];
+    *reinterpret_cast<float2*>(sm + tid * pitch + COLS * 4) = st;
+  }
+}
+
 // Per-thread epilogue parameters: with COLS/4 dividing the thread count, a thread drains the SAME four
 // columns of every row it visits, so bias / LayerScale are two float4 registers loaded once per tile.
 struct ColParams { float4 bias, scale, wscale; };   // wscale: per-output-feature dequant scale of an fp8 weight
-template <int COLS>
+__host__ __device__ __forceinline__ int ln_mode_of(const GemmEpi& e) { return e.ln_part ? LN_PROD : (e.ln_stats ? LN_CONS : LN_NONE); }
+#define LN_DISPATCH(e_, GO_)                                          \
+  switch (ln_mode_of(e_)) {                                           \
+    case LN_PROD: { GO_(LN_PROD) } break;                             \
+    case LN_CONS: { GO_(LN_CONS) } break;                             \
+    default: { GO_(LN_NONE) } break;                                  \
+  }
+
+template <int COLS, int LN = LN_NONE>
 __device__ __forceinline__ ColParams load_col_params(const GemmEpi& e, int n0, int N, int tid) {
   ColParams c;
   const int n = n0 + 4 * (tid % (COLS / 4));
   const bool ok = n < N;
   c.bias = (e.bias && ok) ? *reinterpret_cast<const float4*>(e.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* sc = e.ln_stats ? e.ln_c : e.scale;      // folded LayerNorm (never together with a LayerScale): the column sums c[n]
+  const float* sc = LN == LN_CONS ? e.ln_c : e.scale;      // folded LayerNorm (never together with a LayerScale): the column sums c[n]
   c.scale = (sc && ok) ? *reinterpret_cast<const float4*>(sc + n) : make_float4(1.f, 1.f, 1.f, 1.f);
   c.wscale = (e.w_scale && ok) ? *reinterpret_cast<const float4*>(e.w_scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
   return c;
 }
 
-// sum over the 32 lanes (= 128 output columns) a lane's row group consists of / starts with
-__device__ __forceinline__ float group32_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Sum over a 32-lane half of the wave (= the 128 output columns of a row's statistics group) on DPP adds -- no LDS crossbar, no waits:
+// quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror leave every lane with the sum of its 16-lane row; row_bcast:15 into rows 1
+// and 3 adds the row before.  COMPLETE IN LANES 16..31 AND 48..63 ONLY (the writer lane of a group is its lane 16).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_pick(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float half32_sum_hi(float v) {
+  v += dpp_pick<0xB1, 0xf>(v);
+  v += dpp_pick<0x4E, 0xf>(v);
+  v += dpp_pick<0x141, 0xf>(v);
+  v += dpp_pick<0x140, 0xf>(v);
+  v += dpp_pick<0x142, 0xa>(v);
   return v;
 }
 // the new residual row in the operand format of the GEMM that reads it next (GemmEpi::ln_op; the writers of rowops.hip's LayerNorm)
@@ -141,23 +177,30 @@ __device__ __forceinline__ void ln_store_op(const GemmEpi& e, size_t m, int n, i
 }
 
 // LNF: the folded-LayerNorm producer (GemmEpi::ln_part): every lane stays in the loop (columns n >= N contribute nothing) because the row
-// statistics are reduced across the 32 lanes of a 128-column group
+// statistics are reduced across the 32 lanes of a 128-column group.  One pass: (sum, sum of squares) of v - k, k = the row's PREVIOUS mean
+// (GemmEpi::ln_shift: the residual update moves a row's mean by a fraction of its spread, so the shifted sums carry no cancellation);
+// ln_finalize_kernel turns the groups into (mean, rstd).
 template <int RB, int STEP, int ITER, int C4, bool LNF, typename RowMap>
 __device__ __forceinline__ void drain_resid(const char* sm, int pitch, const GemmEpi& e, const ColParams& cp, int M, int N, int n, int c4, int tid, RowMap rowmap) {
   const int rb = tid / C4;
   const bool nv = !LNF || n < N;
-  const int g0 = n & ~127;                                       // first column of the lane's statistics group
-  const float inv_cnt = LNF ? 1.0f / (float)((N - g0) < 128 ? ((N - g0) > 0 ? (N - g0) : 1) : 128) : 0.f;
+  // lanes 16..31 of a group hold its complete sums (half32_sum_hi): lane 16 + j writes row j of a batch, so the RB rows' statistics leave in ONE
+  // store instruction (the epilogue's time goes with its store instructions, not their bytes)
+  const int wj = (c4 & 31) - 16;
+  const bool writer = LNF && wj >= 0 && wj < RB && (n & ~127) < N;
 #pragma unroll 1
   for (int it = 0; it < ITER; it += RB) {
     float4 r[RB];
     int mm[RB];
+    float kk[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
       mm[j] = rowmap(rb + (it + j) * STEP);
       r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (mm[j] < M && nv) r[j] = *reinterpret_cast<const float4*>(e.resid + (size_t)mm[j] * e.ldr + n);
+      if (LNF) kk[j] = reinterpret_cast<const float2*>(sm + (rb + (it + j) * STEP) * pitch + C4 * 16)->x;      // stage_row_stats
     }
+    float2 mine = make_float2(0.f, 0.f);      // writer lanes: the sums of row wj of this batch
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
       if (!LNF && mm[j] >= M) continue;
@@ -171,19 +214,23 @@ __device__ __forceinline__ void drain_resid(const char* sm, int pitch, const Gem
       if (ok) *reinterpret_cast<float4*>(e.out_f32 + (size_t)mm[j] * e.ldc + n) = v;
       if (LNF) {
         if (ok && e.ln_op) ln_store_op(e, (size_t)mm[j], n, N, v);
-        // (sum, centred square sum) of the row's 128-column group: two-pass inside the group, merged exactly by ln_finalize_kernel
-        const float sum = group32_sum(nv ? (v.x + v.y) + (v.z + v.w) : 0.f);
-        const float mg = sum * inv_cnt;
-        const float a = v.x - mg, b = v.y - mg, c = v.z - mg, d = v.w - mg;
-        const float sq = group32_sum(nv ? (a * a + b * b) + (c * c + d * d) : 0.f);
-        if ((c4 & 31) == 0 && ok) e.ln_part[(size_t)mm[j] * e.ln_npart + (n >> 7)] = make_float2(sum, sq);
+        const float a = v.x - kk[j], b = v.y - kk[j], c = v.z - kk[j], d = v.w - kk[j];
+        const float sum = half32_sum_hi(nv ? (a + b) + (c + d) : 0.f);
+        const float sq = half32_sum_hi(nv ? (a * a + b * b) + (c * c + d * d) : 0.f);
+        if (wj == j) mine = make_float2(sum, sq);
       }
+    }
+    if (LNF && writer) {
+      int mw = mm[0];
+#pragma unroll
+      for (int j = 1; j < RB; ++j) mw = wj == j ? mm[j] : mw;
+      if (mw < M) e.ln_part[(size_t)mw * e.ln_npart + (n >> 7)] = mine;
     }
   }
 }
 
 // rows of the LDS tile map to global rows through `rowmap` (row_l -> m)
-template <int ROWS, int COLS, int NT, typename RowMap>
+template <int ROWS, int COLS, int NT, int LN = LN_NONE, typename RowMap>
 __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const GemmEpi& e, const ColParams& cp, int M, int N,
                                            int n0, int tid, RowMap rowmap) {
   constexpr int C4 = COLS / 4;
@@ -191,7 +238,7 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
   static_assert(C4 % 32 == 0, "a 128-column statistics group is 32 lanes of one wave");
   const int c4 = tid % C4;
   const int n = n0 + 4 * c4;
-  if (n >= N && !e.ln_part) return;
+  if (n >= N && LN != LN_PROD) return;
   if (e.resid && e.out_f32 && e.rows_per_img == 0 && !e.a_scale && !e.a_bs) {
     // The in-place fp32 residual epilogue (out-proj, fc2): a thread visits ROWS / (NT / C4) rows, and with one residual load in flight
     // per thread the pass is a chain of memory latencies (tools/pp_timeline.py: 63 k cycles per 256x256 tile, 15 GB/s per CU).
@@ -201,8 +248,7 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
     constexpr int STEP = NT / C4, ITER = ROWS / STEP;
     static_assert(ROWS % STEP == 0, "whole passes over the tile rows");
     constexpr int RBD = ITER % 4 == 0 ? 4 : (ITER % 2 == 0 ? 2 : 1);
-    if (e.ln_part) { drain_resid<RBD, STEP, ITER, C4, true>(sm, pitch, e, cp, M, N, n, c4, tid, rowmap); return; }
-    drain_resid<RBD, STEP, ITER, C4, false>(sm, pitch, e, cp, M, N, n, c4, tid, rowmap);
+    drain_resid<RBD, STEP, ITER, C4, LN == LN_PROD>(sm, pitch, e, cp, M, N, n, c4, tid, rowmap);
     return;
   }
   if (n >= N) return;
@@ -215,15 +261,15 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
       const float sa = e.a_scale ? e.a_scale[m] : 1.0f;
       v.x *= sa * cp.wscale.x; v.y *= sa * cp.wscale.y; v.z *= sa * cp.wscale.z; v.w *= sa * cp.wscale.w;
     }
-    if (e.ln_stats) {            // folded LayerNorm: (x W'^T - mean c) rstd   (cp.scale holds c; GemmEpi::ln_c)
-      const float2 st = e.ln_stats[m];
+    if (LN == LN_CONS) {         // folded LayerNorm: (x W'^T - mean c) rstd   (cp.scale holds c; GemmEpi::ln_c)
+      const float2 st = *reinterpret_cast<const float2*>(sm + row_l * pitch + C4 * 16);      // stage_row_stats
       v.x = fmaf(-st.x, cp.scale.x, v.x) * st.y; v.y = fmaf(-st.x, cp.scale.y, v.y) * st.y;
       v.z = fmaf(-st.x, cp.scale.z, v.z) * st.y; v.w = fmaf(-st.x, cp.scale.w, v.w) * st.y;
     }
     v.x += cp.bias.x; v.y += cp.bias.y; v.z += cp.bias.z; v.w += cp.bias.w;
     if (e.act == ACT_GELU) { gelu_fast4(v); }
     else if (e.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (!e.ln_stats) { v.x *= cp.scale.x; v.y *= cp.scale.y; v.z *= cp.scale.z; v.w *= cp.scale.w; }
+    if (LN != LN_CONS) { v.x *= cp.scale.x; v.y *= cp.scale.y; v.z *= cp.scale.z; v.w *= cp.scale.w; }
     size_t orow = (size_t)m;
     if (e.rows_per_img > 0) {
       const int b = m / e.rows_per_img, p = m - b * e.rows_per_img;
@@ -287,7 +333,7 @@ __device__ __forceinline__ bool drain8_ok(const GemmEpi& e, int N) {
   return e.out_bf16 && e.out_split <= 0 && !e.resid && e.rows_per_img == 0 && !e.a_scale && !e.a_bs && (N & 7) == 0 && (e.ldc & 7) == 0 &&
          (e.out_split == 0 || ((-e.out_split) & 7) == 0);
 }
-template <int ROWS, int COLS, int NT, typename RowMap>
+template <int ROWS, int COLS, int NT, int LN = LN_NONE, typename RowMap>
 __device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, const GemmEpi& e, int M, int N, int n0, int tid, RowMap rowmap) {
   constexpr int C8 = COLS / 8;
   static_assert(NT % C8 == 0, "a thread must keep its column group");
@@ -296,7 +342,7 @@ __device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, con
   if (n >= N) return;
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0;
   if (e.bias) { b0 = *reinterpret_cast<const float4*>(e.bias + n); b1 = *reinterpret_cast<const float4*>(e.bias + n + 4); }
-  const bool ln = e.ln_stats != nullptr;      // folded LayerNorm: s0 / s1 hold the column sums c[n] instead of a LayerScale
+  constexpr bool ln = LN == LN_CONS;          // folded LayerNorm: s0 / s1 hold the column sums c[n] instead of a LayerScale
   const float* sc = ln ? e.ln_c : e.scale;
   if (sc) { s0 = *reinterpret_cast<const float4*>(sc + n); s1 = *reinterpret_cast<const float4*>(sc + n + 4); }
 #pragma unroll
@@ -305,13 +351,20 @@ __device__ __forceinline__ void drain_tile_bf16x8(const char* sm, int pitch, con
     if (m >= M) continue;
     float4 v = *reinterpret_cast<const float4*>(sm + row_l * pitch + c8 * 32);
     float4 u = *reinterpret_cast<const float4*>(sm + row_l * pitch + c8 * 32 + 16);
-    if (ln) {                     // (x W'^T - mean c) rstd
-      const float2 st = e.ln_stats[m];
-      v.x = fmaf(-st.x, s0.x, v.x) * st.y; v.y = fmaf(-st.x, s0.y, v.y) * st.y; v.z = fmaf(-st.x, s0.z, v.z) * st.y; v.w = fmaf(-st.x, s0.w, v.w) * st.y;
-      u.x = fmaf(-st.x, s1.x, u.x) * st.y; u.y = fmaf(-st.x, s1.y, u.y) * st.y; u.z = fmaf(-st.x, s1.z, u.z) * st.y; u.w = fmaf(-st.x, s1.w, u.w) * st.y;
+    if (ln) {                     // rstd acc + (b' - mean rstd c): two packed FMAs per pair where the plain epilogue has one packed add
+      const float2 st = *reinterpret_cast<const float2*>(sm + row_l * pitch + COLS * 4);      // stage_row_stats
+      const f32x2_t t = (f32x2_t)(-st.x * st.y), rs = (f32x2_t)(st.y);
+#define LN_PAIR_(va, vb, ca, cb, ba, bb)                                                                         \
+      { const f32x2_t c_ = {ca, cb}, b_ = {ba, bb}, a_ = {va, vb};                                                \
+        const f32x2_t o_ = __builtin_elementwise_fma(a_, rs, __builtin_elementwise_fma(t, c_, b_));               \
+        va = o_.x; vb = o_.y; }
+      LN_PAIR_(v.x, v.y, s0.x, s0.y, b0.x, b0.y) LN_PAIR_(v.z, v.w, s0.z, s0.w, b0.z, b0.w)
+      LN_PAIR_(u.x, u.y, s1.x, s1.y, b1.x, b1.y) LN_PAIR_(u.z, u.w, s1.z, s1.w, b1.z, b1.w)
+#undef LN_PAIR_
+    } else {
+      v.x += b0.x; v.y += b0.y; v.z += b0.z; v.w += b0.w;
+      u.x += b1.x; u.y += b1.y; u.z += b1.z; u.w += b1.w;
     }
-    v.x += b0.x; v.y += b0.y; v.z += b0.z; v.w += b0.w;
-    u.x += b1.x; u.y += b1.y; u.z += b1.z; u.w += b1.w;
     if (e.act == ACT_GELU) {
       gelu_fast4(v); gelu_fast4(u);
     } else if (e.act == ACT_RELU) {

@@ -63,7 +63,7 @@ extern "C" int dod_debug_pp_stamps(void* dev_buf) {
 // DC = true: the two LDS-DMA instructions of a phase are issued from inside the COMPUTE segment (between its MFMAs, whose issue slots
 // have slack: an MFMA holds the issue port for half its 16 cycles) instead of the LOAD segment, whose length -- not the MFMAs' --
 // paces the ping-pong once it exceeds the partner's COMPUTE; the counted wait of LOAD 3 then leaves vmcnt(2) (one plane) in flight.
-template <bool X3, bool DC>
+template <bool X3, bool DC, int LN>
 __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __restrict__ A, int lda,
                                                                const bf16_t* __restrict__ W, int ldw, int M, int N,
                                                                int K, GemmEpi e_, int GM) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
   if (stamps) ts2 = __builtin_amdgcn_s_memtime();
 
   constexpr int PITCH = PPN * 4 + 16;
-  const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
+  const ColParams cp = load_col_params<PPN, LN>(e, n0, N, tid);
   const bool wide = drain8_ok(e, N);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -219,10 +219,11 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
         const f32x4 a = acc[pass * 4 + ii][j];
         *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
       }
+    auto rowmap = [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); };
+    stage_row_stats<128, PPN, LN>(smem, PITCH, e, M, tid, rowmap);
     __syncthreads();
-    if (wide) drain_tile_bf16x8<128, PPN, 512>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
-    else drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                                   [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+    if (wide) drain_tile_bf16x8<128, PPN, 512, LN>(smem, PITCH, e, M, N, n0, tid, rowmap);
+    else drain_tile<128, PPN, 512, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);
   }
   if (stamps && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -275,6 +276,7 @@ __device__ __forceinline__ void h2_cvt8(const bf16x8& raw, float inv_scale, int&
   d0 = __builtin_bit_cast(int, r0); d1 = __builtin_bit_cast(int, r1);
 }
 
+template <int LN>
 __global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __restrict__ A, int lda, const char* __restrict__ W, int ldw,
                                                               int M, int N, int K, GemmEpi e_, int GM) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __rest
   if (stamps) ts2 = __builtin_amdgcn_s_memtime();
 
   constexpr int PITCH = PPN * 4 + 16;
-  const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
+  const ColParams cp = load_col_params<PPN, LN>(e, n0, N, tid);
   const bool wide = drain8_ok(e, N);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -458,10 +460,11 @@ __global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __rest
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
       for (int j = 0; j < 2; ++j) stage_acc(smem, PITCH, grp_ * 64 + ii * 32 + lr, wq * 64 + j * 32, acc[pass * 2 + ii][j], lg);
+    auto rowmap = [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); };
+    stage_row_stats<128, PPN, LN>(smem, PITCH, e, M, tid, rowmap);
     __syncthreads();
-    if (wide) drain_tile_bf16x8<128, PPN, 512>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
-    else drain_tile<128, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                                   [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); });
+    if (wide) drain_tile_bf16x8<128, PPN, 512, LN>(smem, PITCH, e, M, N, n0, tid, rowmap);
+    else drain_tile<128, PPN, 512, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);
   }
   if (stamps && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -492,8 +495,10 @@ static void ppm_attr() {      // > 64 KiB of dynamic LDS: once per device
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
+#define ATTR_(LN_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<false, false, LN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP); \
+                   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppm_256x256_kernel<true, false, LN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP);
+    ATTR_(LN_NONE) ATTR_(LN_CONS) ATTR_(LN_PROD)
+#undef ATTR_
     attr_set[dev] = true;
   }
 }
@@ -507,7 +512,9 @@ int launch_gemm_bf16_ppm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int
   ppm_attr();
   int gm = gemm_tile_mode();
   const int tiles = wres_grid(M, N, &gm);
-  hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, false>), dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
+#define GO_(LN_) hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, false, LN_>), dim3(tiles), dim3(512), LDSPP, s, A, lda, W, ldw, M, N, K, e, gm);
+  LN_DISPATCH(e, GO_)
+#undef GO_
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -521,7 +528,9 @@ int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int 
   ppm_attr();
   int gm = gemm_tile_mode();
   const int tiles = wres_grid(M, N, &gm);
-  hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, false>), dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e, gm);
+#define GO_(LN_) hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, false, LN_>), dim3(tiles), dim3(512), LDSPP, s, A2, lda, W2, ldw, M, N, K, e, gm);
+  LN_DISPATCH(e, GO_)
+#undef GO_
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -532,7 +541,9 @@ static void h2_attr() {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSH2);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_256x256_kernel<LN_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSH2);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_256x256_kernel<LN_CONS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSH2);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_256x256_kernel<LN_PROD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSH2);
     attr_set[dev] = true;
   }
 }
@@ -549,7 +560,9 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
   h2_attr();
   const int gm = gemm_tile_mode();
   const int tiles = ((M + PPM - 1) / PPM) * ((N + PPN - 1) / PPN);
-  hipLaunchKernelGGL(gemm_h2_256x256_kernel, dim3(tiles), dim3(512), LDSH2, s, (const char*)A, lda, (const char*)W, ldw, M, N, K, e, gm);
+#define GO_(LN_) hipLaunchKernelGGL(gemm_h2_256x256_kernel<LN_>, dim3(tiles), dim3(512), LDSH2, s, (const char*)A, lda, (const char*)W, ldw, M, N, K, e, gm);
+  LN_DISPATCH(e, GO_)
+#undef GO_
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -559,6 +572,7 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
 // short last round are cut off, their tiles K-split S ways in ONE launch (grid.y = slice: S CUs per tile, fp32 partial slabs), and
 // a reduce + epilogue launch sums the slabs into an LDS tile and drains it with the GEMMs' own epilogue code.
 #define KSR_ROWS 16      // rows per workgroup of the reduce launch: 16 x 256 outputs, so that a 384-row remainder still spreads over 72 CUs
+template <int LN>
 __global__ __launch_bounds__(512) void gemm_ksplit_reduce_kernel(const float* __restrict__ part, long long slice_stride, int S, int R, int N,
                                                                  GemmEpi e, int m_base, int M) {
   __shared__ __attribute__((aligned(16))) char smem[KSR_ROWS * (PPN * 4 + 16)];
@@ -579,10 +593,12 @@ __global__ __launch_bounds__(512) void gemm_ksplit_reduce_kernel(const float* __
     }
     *reinterpret_cast<float4*>(smem + rl * PITCH + c4 * 16) = acc;
   }
+  auto rowmap = [&](int row_l) { return m_base + r0 + row_l; };
+  stage_row_stats<KSR_ROWS, PPN, LN>(smem, PITCH, e, M, tid, rowmap);
   __syncthreads();
-  const ColParams cp = load_col_params<PPN>(e, n0, N, tid);
-  if (drain8_ok(e, N)) drain_tile_bf16x8<KSR_ROWS, PPN, 512>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m_base + r0 + row_l; });
-  else drain_tile<KSR_ROWS, PPN, 512>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m_base + r0 + row_l; });
+  const ColParams cp = load_col_params<PPN, LN>(e, n0, N, tid);
+  if (drain8_ok(e, N)) drain_tile_bf16x8<KSR_ROWS, PPN, 512, LN>(smem, PITCH, e, M, N, n0, tid, rowmap);
+  else drain_tile<KSR_ROWS, PPN, 512, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);
 }
 
 // scratch: TAIL_SLOTS slabs per device, handed to launching streams least-recently-used first (a forward may run as concurrent
@@ -709,16 +725,18 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   if (kind == 2) {
     h2_attr();
     const char* Ar = (const char*)A + (size_t)Mmain * lda;
-    hipLaunchKernelGGL(gemm_h2_256x256_kernel, dim3(tiles_r, S), dim3(512), LDSH2, s, Ar, lda, (const char*)W, ldw, R, N, K, es, gm);
+    hipLaunchKernelGGL(gemm_h2_256x256_kernel<LN_NONE>, dim3(tiles_r, S), dim3(512), LDSH2, s, Ar, lda, (const char*)W, ldw, R, N, K, es, gm);
   } else {
     ppm_attr();
     const bf16_t* Ar = (const bf16_t*)A + (size_t)Mmain * lda;
-    if (kind == 1) hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, false>), dim3(tiles_r, S), dim3(512), LDSPP, s, Ar, lda, (const bf16_t*)W, ldw, R, N, K, es, gm);
-    else hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, false>), dim3(tiles_r, S), dim3(512), LDSPP, s, Ar, lda, (const bf16_t*)W, ldw, R, N, K, es, gm);
+    if (kind == 1) hipLaunchKernelGGL((gemm_ppm_256x256_kernel<true, false, LN_NONE>), dim3(tiles_r, S), dim3(512), LDSPP, s, Ar, lda, (const bf16_t*)W, ldw, R, N, K, es, gm);
+    else hipLaunchKernelGGL((gemm_ppm_256x256_kernel<false, false, LN_NONE>), dim3(tiles_r, S), dim3(512), LDSPP, s, Ar, lda, (const bf16_t*)W, ldw, R, N, K, es, gm);
   }
   if (hipGetLastError() != hipSuccess) return 3;
   // ---- reduce + the caller's epilogue on global rows Mmain..M-1
   ++g_tail_splits;
-  hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3((R + KSR_ROWS - 1) / KSR_ROWS, tiles_n), dim3(512), 0, s, scratch, (long long)slab, S, R, N, e, Mmain, M);
+#define GO_(LN_) hipLaunchKernelGGL(gemm_ksplit_reduce_kernel<LN_>, dim3((R + KSR_ROWS - 1) / KSR_ROWS, tiles_n), dim3(512), 0, s, scratch, (long long)slab, S, R, N, e, Mmain, M);
+  LN_DISPATCH(e, GO_)
+#undef GO_
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

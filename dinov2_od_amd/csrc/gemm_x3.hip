@@ -27,7 +27,7 @@ __device__ __forceinline__ int x3_swz(int row, int chunk) { return chunk ^ (((ro
 
 // PLAIN = true: the same structure as an ordinary bf16 GEMM with BK = 64 -- the second plane of each operand holds k 32..63
 // of the K-tile instead of the lo halves, two products per K-tile (experiment / DINODET_GEMM_TILE=x).
-template <bool PLAIN>
+template <bool PLAIN, int LN>
 __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __restrict__ A2, int lda,
                                                                const bf16_t* __restrict__ W2, int ldw, int M, int N,
                                                                int K, GemmEpi e, int GM) {
@@ -110,27 +110,26 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
   }
   // epilogue: two passes of 128 tile rows through a 128 x 256 fp32 LDS tile (pitch +16 B)
   constexpr int PITCH = X3N * 4 + 16;
-  const ColParams cp = load_col_params<X3N>(e, n0, N, tid);
+  const ColParams cp = load_col_params<X3N, LN>(e, n0, N, tid);
   const bool wide = drain8_ok(e, N);
-  // (the pass loop stays ROLLED -- one copy of the drain code -- and the accumulators are staged from statically indexed registers in
-  // either branch: left to the unroller, a body that outgrows its threshold turns `acc[pass * 2 + ii]` into a scratch array)
-#define X3_STAGE_ACC(P)                                                                                                     \
-  _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                                          \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                         \
-      const int row_l = wm * 32 + ii * 16 + l15;                                                                            \
-      const int col = wn * 64 + j * 16 + 4 * l4;                                                                            \
-      const f32x4 a = acc[(P) * 2 + ii][j];                                                                                 \
-      *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);                     \
-    }
-#pragma unroll 1
+#pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (pass == 0) { X3_STAGE_ACC(0) } else { X3_STAGE_ACC(1) }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row_l = wm * 32 + ii * 16 + l15;
+        const int col = wn * 64 + j * 16 + 4 * l4;
+        const f32x4 a = acc[pass * 2 + ii][j];
+        *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+    auto rowmap = [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); };
+    stage_row_stats<128, X3N, LN>(smem, PITCH, e, M, tid, rowmap);
     __syncthreads();
-    if (wide) drain_tile_bf16x8<128, X3N, 1024>(smem, PITCH, e, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
-    else drain_tile<128, X3N, 1024>(smem, PITCH, e, cp, M, N, n0, tid,
-                                    [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+    if (wide) drain_tile_bf16x8<128, X3N, 1024, LN>(smem, PITCH, e, M, N, n0, tid, rowmap);
+    else drain_tile<128, X3N, 1024, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);
   }
 }
 
@@ -160,8 +159,10 @@ static void x3_attr() {      // > 64 KiB of dynamic LDS: once per device
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
+#define ATTR_(LN_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<false, LN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3); \
+                   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_256x256_kernel<true, LN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX3);
+    ATTR_(LN_NONE) ATTR_(LN_CONS) ATTR_(LN_PROD)
+#undef ATTR_
     attr_set[dev] = true;
   }
 }
@@ -186,7 +187,9 @@ int launch_gemm_x3(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, 
   x3_attr();
   const int gm = gemm_tile_mode();
   const int tiles = ((M + X3M - 1) / X3M) * ((N + X3N - 1) / X3N);
-  hipLaunchKernelGGL(gemm_x3_256x256_kernel<false>, dim3(tiles), dim3(1024), LDSX3, s, A2, lda, W2, ldw, M, N, K, e, gm);
+#define GO_(LN_) hipLaunchKernelGGL((gemm_x3_256x256_kernel<false, LN_>), dim3(tiles), dim3(1024), LDSX3, s, A2, lda, W2, ldw, M, N, K, e, gm);
+  LN_DISPATCH(e, GO_)
+#undef GO_
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -196,6 +199,8 @@ int launch_gemm_bf16_k64(const bf16_t* A, int lda, const bf16_t* W, int ldw, int
   x3_attr();
   const int gm = gemm_tile_mode();
   const int tiles = ((M + X3M - 1) / X3M) * ((N + X3N - 1) / X3N);
-  hipLaunchKernelGGL(gemm_x3_256x256_kernel<true>, dim3(tiles), dim3(1024), LDSX3, s, A, lda, W, ldw, M, N, K, e, gm);
+#define GO_(LN_) hipLaunchKernelGGL((gemm_x3_256x256_kernel<true, LN_>), dim3(tiles), dim3(1024), LDSX3, s, A, lda, W, ldw, M, N, K, e, gm);
+  LN_DISPATCH(e, GO_)
+#undef GO_
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -260,21 +260,17 @@ int launch_rowstats(const float* x, int rows, int D, float eps, void* op, int op
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
-// group statistics -> (mean, rstd): mean = sum_g sum_g / D;  M2 = sum_g [ sq_g + n_g (mean_g - mean)^2 ]  (exact merge of centred sums)
+// group sums of (x - k) and (x - k)^2, k = stats[row].x on entry (the shift the producer subtracted: the row's previous mean) ->
+// mean = k + S / D,  var = Q / D - (S / D)^2  (S / D is the CHANGE of the mean: a fraction of the spread, so nothing cancels)
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, int npart, int rows, int D, float eps, float2* __restrict__ stats) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   const float2* p = part + (size_t)row * npart;
-  float tot = 0.f;
-  for (int g = 0; g < npart; ++g) tot += p[g].x;
-  const float mean = tot / (float)D;
-  float m2 = 0.f;
-  for (int g = 0; g < npart; ++g) {
-    const int ng = (D - 128 * g) < 128 ? (D - 128 * g) : 128;
-    const float d = p[g].x / (float)ng - mean;
-    m2 += p[g].y + (float)ng * d * d;
-  }
-  stats[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)D + eps));
+  float S = 0.f, Q = 0.f;
+  for (int g = 0; g < npart; ++g) { S += p[g].x; Q += p[g].y; }
+  const float k = stats[row].x, dm = S / (float)D;
+  const float var = fmaxf(Q / (float)D - dm * dm, 0.f);
+  stats[row] = make_float2(k + dm, 1.0f / sqrtf(var + eps));
 }
 
 int launch_ln_finalize(const float2* part, int npart, int rows, int D, float eps, float2* stats, hipStream_t s) {

@@ -210,14 +210,18 @@ int dod_op_linear_h2(const void* A, const void* W, const void* wexp, int M, int 
  * W' = W diag(gamma), c[n] = sum_k W'[n][k] and b' = b + W beta,   LN(x) W^T + b = rstd (x W'^T - mean c) + b'.
  *   consumer (stats, csum set): A holds the residual rows x themselves in the family's operand format, W holds W', bias holds b';
  *   producer (part set; out_layout 0 with a residual): beside the fp32 rows it writes them in the family's operand format to op_out
- *     ([M, N] bf16 / pair layout [M, 2N] / H2 rows) and (sum, centred sum of squares) per 128-column group to part [M][ceil(N / 128)][2];
- * dod_op_ln_finalize merges the groups into stats [M][2] = (mean, rstd); dod_op_rowstats: x -> operand copy + stats (the first block).
+ *     ([M, N] bf16 / pair layout [M, 2N] / H2 rows) and (sum, sum of squares) of (row - shift[m][0]) per 128-column group to
+ *     part [M][ceil(N / 128)][2]; shift [M][2] (or NULL = 0): a value near the row's mean -- the forward passes the row's previous
+ *     statistics, which makes the one-pass sums free of cancellation;
+ * dod_op_ln_finalize turns the groups into stats [M][2] = (mean, rstd); on entry stats[m][0] must hold the shift the producer used
+ * (the same buffer, or zeros); dod_op_rowstats: x -> operand copy + stats (the first block).
  * family: DOD_PREC_BF16 / DOD_PREC_BF16X3 / DOD_PREC_FP16X2; A / W / wexp / out_layout as in dod_op_linear / _x3 / _h2 (bf16: lda = ldw = K). */
 typedef struct dod_ln_fold {
   const void* stats;
   const float* csum;
   void* op_out;
   void* part;
+  const void* shift;
 } dod_ln_fold;
 int dod_op_linear_ln(int family, const void* A, const void* W, const void* wexp, int M, int N, int K, const float* bias, const float* scale,
                      const float* resid, int ldr, void* out, int out_layout, int ldc, int act, const dod_ln_fold* ln, void* stream);

@@ -80,6 +80,28 @@ def test_bench_self_launches_ranks_and_gathers(tmp_path):
     assert j["data"] == "rehearsal-cpu" and j["metric"].startswith("REHEARSAL")
     assert j["global64_sharded"]["per_gpu_batch"] == 32 and j["global64_sharded"]["scaling"] == "strong"
     assert j["steps"] == 3 and j["value"] > 0
+    # what the first unattended 8-GPU run must show: every rank's own clock and every rank's detections checked against the oracle
+    pr = j["per_rank"]
+    assert [r_["rank"] for r_ in pr["ms_per_step"]] == [0, 1] and all(r_["ms_per_step"] > 0 for r_ in pr["ms_per_step"])
+    assert pr["spread_ms"] >= 0 and pr["slowest_rank"] in (0, 1)
+    chk = pr["gpu_vs_oracle"]
+    assert chk["all_in_gate"] and [r_["global_image"] for r_ in chk["ranks"]] == [0, 64]
+
+
+def test_bench_fails_when_a_rank_leaves_the_gate(tmp_path):
+    """a rank whose detections are wrong must fail the JOB (non-zero exit of `bench.py --gpus N`), not only show up in the JSON"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_REHEARSE_BREAK_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse-cpu", "--no-extras"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode != 0
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    ranks = j["per_rank"]["gpu_vs_oracle"]["ranks"]
+    assert ranks[0]["in_gate"] and not ranks[1]["in_gate"] and not j["per_rank"]["gpu_vs_oracle"]["all_in_gate"]
 
 
 def test_launcher_propagates_a_failing_rank(tmp_path):

@@ -62,9 +62,10 @@ def _sample(M):
 SHAPES = [(300, 384, 384), (517, 192, 640), (2740, 768, 768), (64 * 1370, 768, 768), (64 * 1370, 768, 3072), (8224, 768, 3072)]
 
 
+@pytest.mark.parametrize("shifted", [True, False], ids=["shift", "noshift"])
 @pytest.mark.parametrize("fam", list(FAM))
 @pytest.mark.parametrize("M,D,K", SHAPES, ids=[f"{m}x{d}x{k}" for m, d, k in SHAPES])
-def test_residual_epilogue_emits_operand_rows_and_statistics(fam, M, D, K):
+def test_residual_epilogue_emits_operand_rows_and_statistics(fam, M, D, K, shifted):
     """out-proj (K = D) / fc2 (K = 4D) with the in-place fp32 residual + LayerScale epilogue (modeling_dinov2.py:367-370, 377-380)"""
     L = nat.lib()
     nat.check(L.dod_reserve_gemm_scratch(64 << 20))      # as dod_finalize_weights does: the K >= 2048 launches take the tail split (gemm_pp.hip)
@@ -86,8 +87,11 @@ def test_residual_epilogue_emits_operand_rows_and_statistics(fam, M, D, K):
     npart = (D + 127) // 128
     part = torch.full((M, npart, 2), float("nan"), device="cuda")
     op = torch.zeros(M, D if fam == "bf16" else 2 * D, dtype=torch.bfloat16, device="cuda")
-    stats = torch.empty(M, 2, device="cuda")
-    ln = nat.DodLnFold(None, None, op.data_ptr(), part.data_ptr())
+    # the shift: as in the forward, the statistics the row had BEFORE the update (here: of x0); `shifted=False` runs with no shift at all
+    stats = torch.zeros(M, 2, device="cuda")
+    if shifted:
+        stats[:, 0] = x0.mean(-1)
+    ln = nat.DodLnFold(None, None, op.data_ptr(), part.data_ptr(), stats.data_ptr() if shifted else None)
     nat.check(L.dod_op_linear_ln(FAM[fam], nat.ptr(Aop), nat.ptr(Wop), nat.ptr(wexp), M, D, K, nat.ptr(bias), nat.ptr(ls), nat.ptr(x), D,
                                  nat.ptr(x), 0, D, 0, C.byref(ln), nat.stream_ptr()))
     nat.check(L.dod_op_ln_finalize(nat.ptr(part), M, D, EPS, nat.ptr(stats), nat.stream_ptr()))
@@ -99,8 +103,10 @@ def test_residual_epilogue_emits_operand_rows_and_statistics(fam, M, D, K):
     rstd = 1.0 / torch.sqrt(((xd - mean[:, None]) ** 2).mean(-1) + EPS)
     e_mean = float((stats[:, 0].double() - mean).abs().max() / xd.abs().max())
     e_rstd = float(((stats[:, 1].double() - rstd) / rstd).abs().max())
-    print(f"{fam} M={M} D={D} K={K}: mean {e_mean:.1e} rstd {e_rstd:.1e}")
-    assert e_mean < 2e-7 and e_rstd < 2e-6
+    print(f"{fam} M={M} D={D} K={K} shifted={shifted}: mean {e_mean:.1e} rstd {e_rstd:.1e}")
+    # one-pass sums: with the shift nothing cancels (fp32 rounding of a 768-term sum); without it the variance loses log2(1 + mean^2 / var)
+    # bits -- these rows have |mean| ~ std, so still ~1e-6
+    assert e_mean < 3e-7 and e_rstd < (3e-6 if shifted else 1e-5)
     rows = _sample(M)
     got = _decode_rows(op, fam, D, rows)
     want = x[rows].cpu()
@@ -135,7 +141,7 @@ def test_folded_consumer_equals_layernorm_then_linear(fam, M, N, D, act):
     Wop, wexp = _operand(Wp, fam, weight=True)
     out_layout = 1 if fam == "bf16" else (3 if (fam == "fp16x2" and act == "gelu" and N % 32 == 0) else 2)
     out = torch.zeros(M, N if fam == "bf16" else 2 * N, dtype=torch.bfloat16, device="cuda")
-    ln = nat.DodLnFold(stats.data_ptr(), csum.data_ptr(), None, None)
+    ln = nat.DodLnFold(stats.data_ptr(), csum.data_ptr(), None, None, None)
     nat.check(L.dod_op_linear_ln(FAM[fam], nat.ptr(xop), nat.ptr(Wop), nat.ptr(wexp), M, N, D, nat.ptr(bp), None, None, 0, nat.ptr(out), out_layout,
                                  N if fam == "bf16" else 2 * N, nat.ACT[act], C.byref(ln), nat.stream_ptr()))
     torch.cuda.synchronize()
@@ -157,7 +163,7 @@ def test_folded_consumer_equals_layernorm_then_linear(fam, M, N, D, act):
         else:
             o = out[rows].double().cpu()
             got = o[:, :N] + o[:, N:]
-        tol = 5e-5
+        tol = 5e-5 if fam == "bf16x3" else 1e-4      # H2: 5e-5-grade on O(1) operands; these rows carry an offset ~ their spread
     if act == "gelu":
         want = torch.nn.functional.gelu(want)
     err = rel_err(got.numpy(), want.numpy())

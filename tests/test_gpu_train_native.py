@@ -10,7 +10,7 @@ import torch
 
 from dinov2_od_amd import _native as nat, synth
 from tests import cases
-from tests.cases import rel_err
+from tests.cases import rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -100,6 +100,35 @@ def test_native_decoder_backward_matches_composite_autograd(case):
             assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-5, k     # B*Q terms of both signs: 2.4e-6 seen on one box, 1e-6 typical)
 
 
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[4]], ids=lambda c: f"Dd{c[0]}_Q{c[2]}_N{c[8]}")
+def test_deterministic_mode_is_bit_reproducible_and_agrees_with_the_fast_step(case):
+    """DINODET_DETERMINISTIC=1 / test option "deterministic" (dec_train.hip det_mode): every reduction the fast training step merges with
+    fp32 atomics -- K-split gradient products, bias sums, LayerNorm gradients, the deformable sampling adjoint's scatter and its shared
+    reference-logit columns -- runs in a fixed order.  Three runs of the same step give bit-identical gradients; the fast step (whose
+    runs agree with each other to ~1e-6) agrees with them to 1e-5."""
+    from tests import gpu_util as G
+    Dd, Hd, Q, layers, F, C, P, B, N = case
+    dc = cases.dec_cfg(True, Dd, Hd, Q, layers, F, C, P)
+    m = _decoder(dc)
+    mem = G.to_gpu(synth.normal(3, f"memory.det.{N}.{Dd}", (B, N, Dd), MEM_STD.get(Dd, 1.0)))
+    wl = G.to_gpu(synth.normal(5, "det.wl", (B, Q, C), 1.0))
+    wb = G.to_gpu(synth.normal(5, "det.wb", (B, Q, 4), 1.0))
+    fast = _run(m, mem, wl, wb, native=True)
+    nat.set_option("deterministic", 1)
+    try:
+        runs = [_run(m, mem, wl, wb, native=True) for _ in range(3)]
+    finally:
+        nat.set_option("deterministic", -1)
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2]), "outputs / d(memory) differ between runs"
+        assert set(r[3]) == set(runs[0][3])
+        for k in r[3]:
+            assert torch.equal(r[3][k], runs[0][3][k]), f"{k}: not bit-reproducible in deterministic mode"
+    worst = max((rel_err(fast[3][k].cpu().numpy(), runs[0][3][k].cpu().numpy()), k) for k in fast[3])
+    print(f"deterministic vs fast step {case}: worst gradient {worst[0]:.2e} ({worst[1]}); d(memory) {rel_err(fast[2].cpu().numpy(), runs[0][2].cpu().numpy()):.2e}")
+    assert worst[0] < 1e-5 and rel_err(fast[2].cpu().numpy(), runs[0][2].cpu().numpy()) < 1e-5
+
+
 def test_native_decoder_dropout_masks_are_consistent_and_seeded():
     """dropout 0.1 at the reference's five sites: the forward is a deterministic function of the seed, the drop rate is right, and
     the backward applies the SAME masks (directional finite difference of the loss against the analytic gradient)."""
@@ -181,6 +210,17 @@ def test_detector_train_step_uses_the_native_decoder_backward():
             os.environ.pop("DINODET_NATIVE_TRAIN", None)
     l0, g0 = run(False)
     l1, g1 = run(True)
+    # the whole native step (backbone tail with its LoRA gradient kernels + decoder) in deterministic mode: bit-identical between runs
+    nat.set_option("deterministic", 1)
+    try:
+        ld, gd = run(True)
+        ld2, gd2 = run(True)
+    finally:
+        nat.set_option("deterministic", -1)
+    assert torch.equal(ld, ld2) and set(gd) == set(gd2) == set(g1)
+    for k in gd:
+        assert torch.equal(gd[k], gd2[k]), f"{k}: not bit-reproducible in deterministic mode"
+        assert rel_err(gd[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-5, k
     assert rel_err(l1.cpu().numpy(), l0.cpu().numpy()) < 1e-4
     assert set(g0) == set(g1) and any("lora_A" in k for k in g1) and any(k.startswith("backbone.projection") for k in g1)
     for k in g0:
@@ -259,6 +299,9 @@ def test_native_backbone_tail_backward_matches_composite_autograd(variant, R, B)
     print(f"backbone tail {variant} R={R}: memory {rel_err(m1.cpu().numpy(), m0.cpu().numpy()):.2e}, worst gradient {worst[0]} {worst[1]:.2e}")
 
 
+K_F64 = 1.5      # distance to float64 allowed over the reference's own fp32 distance, per tensor
+
+
 @pytest.mark.parametrize("name", sorted(cases.G9_CASES))
 @pytest.mark.parametrize("native", [True, False], ids=["native", "composite"])
 def test_train_step_gradients_match_the_reference_backward(name, native):
@@ -287,16 +330,35 @@ def test_train_step_gradients_match_the_reference_backward(name, native):
     el, eb = rel_err(o["pred_logits"].detach().cpu().numpy(), g["pred_logits"]), rel_err(o["pred_boxes"].detach().cpu().numpy(), g["pred_boxes"])
     assert el < 1e-3 and eb < 1e-3
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-3 * max(1.0, abs(float(g["loss"])))
-    # fp32 on both sides, different summation orders.  The default 768-wide decoder stacks three tied layers whose sampling gradient
-    # is only piecewise smooth: a sample within rounding of a cell border re-routes its gradient, and a ReLU unit within rounding of
-    # zero flips its row -- isolated entries move (3e-3 of a tensor's max was measured), the tensor as a whole does not: there the
-    # criterion is the L2 error of each probe and of each whole tensor's norm, as in test_native_decoder_backward_matches_composite_autograd
-    # Measured: the PyTorch-ROCm composite and the native step BOTH sit 1.2-1.7e-2 (probe L2; 1.3e-2 on the tensor norm) from the CPU
-    # evaluation on the same LoRA tensors of block 11 and within 1e-2 on every other tensor -- the fp32 conditioning of that decoder, not a kernel property
-    # (cfg1 and the dense branch agree with the reference to 2-6e-5 on every tensor).
+    # cfg1 and the dense branch agree with the reference's fp32 gradients to 2-6e-5 on every tensor: held at 2e-4 max-relative
     deep = "vitb" in name
-    worst = cases.g9_check(m, g, 3e-2 if deep else 2e-4, 3e-2 if deep else 2e-4, metric=cases.rel_l2 if deep else None)
-    print(f"{name} {'native' if native else 'composite'}: forward logits {el:.2e} boxes {eb:.2e}; worst gradient probe {worst[0]:.2e} ({worst[1]})")
+    if not deep:
+        worst = cases.g9_check(m, g, 2e-4, 2e-4)
+        print(f"{name} {'native' if native else 'composite'}: forward logits {el:.2e} boxes {eb:.2e}; worst gradient probe {worst[0]:.2e} ({worst[1]})")
+        return
+    # The default 768-wide decoder: arbitrated by the REFERENCE's own modules evaluated in float64 (golden g9_grad_vitb_224_f64, the same
+    # inputs through `.double()`).  The reference's fp32 CPU backward itself sits 2-5e-3 (probe rel-L2) from that float64 evaluation on the
+    # LoRA tensors of blocks 10 / 11 -- three tied layers whose sampling gradient is piecewise smooth: that is the conditioning, measured, and
+    # it is the per-tensor FLOOR an fp32 evaluation is held to here:  d(this step, float64) <= K * max(d(reference fp32, float64), 1e-4).
+    g64 = cases.golden(name + "_f64")
+    params = dict(m.named_parameters())
+    rows, bad = [], []
+    for k in map(str, g["trainable_with_grad"]):
+        assert params[k].grad is not None, k
+        pr, st = cases.grad_probe(params[k].grad.detach().cpu().numpy())
+        d_gpu = max(rel_l2(pr, g64["grad:" + k]), abs(st[2] - g64["stat:" + k][2]) / g64["stat:" + k][2])
+        floor = max(rel_l2(g["grad:" + k], g64["grad:" + k]), abs(g["stat:" + k][2] - g64["stat:" + k][2]) / g64["stat:" + k][2], 1e-4)
+        rows.append((d_gpu / floor, d_gpu, floor, k))
+        if not d_gpu <= K_F64 * floor:
+            bad.append((k, d_gpu, floor))
+    rows.sort(reverse=True)
+    for ratio, d_gpu, floor, k in rows[:6]:
+        print(f"{name} {'native' if native else 'composite'} {k}: {d_gpu:.2e} from float64 (reference fp32: {floor:.2e}; ratio {ratio:.2f})")
+    print(f"{name} {'native' if native else 'composite'}: forward logits {el:.2e} boxes {eb:.2e}; median ratio {sorted(r[0] for r in rows)[len(rows) // 2]:.2f}")
+    assert not bad, f"{len(bad)} gradients further than {K_F64} x the reference's own fp32 distance from float64: {bad[:6]}"
+    for k in g["trainable_without_grad"]:
+        p_ = params[str(k)]
+        assert p_.grad is None or float(p_.grad.abs().sum()) == 0.0, k
 
 
 DENSE_CASES = [  # Dd, Hd, Q, layers, F, C, B, N

@@ -6,10 +6,15 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r4e1
 mkdir -p $O
 cd $R
-timeout -k 10 700 python -m pytest tests/test_gpu_lnfold.py tests/test_gpu_forward.py tests/test_gpu_timed_shapes.py -x -q -m gpu -k "not giant" > $O/tests.log 2>&1
+timeout -k 10 300 python -m pytest tests/test_gpu_lnfold.py -x -q -m gpu > $O/tests_ops.log 2>&1
 rc=$?
-tail -15 $O/tests.log
-if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "tests ended with rc $rc: no further GPU step"; exit $rc; fi
+tail -6 $O/tests_ops.log
+if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "op tests ended with rc $rc: no further GPU step"; exit $rc; fi
+DINODET_LN_FOLD=1 timeout -k 10 700 python -m pytest tests/test_gpu_forward.py tests/test_gpu_timed_shapes.py -x -q -m gpu -k "not giant and not fp32" > $O/tests_fwd.log 2>&1
+rc2=$?
+tail -12 $O/tests_fwd.log
+if [ $rc2 -ne 0 ] && [ $rc2 -ne 1 ]; then echo "forward tests ended with rc $rc2: no further GPU step"; exit $rc2; fi
+[ $rc -eq 0 ] && rc=$rc2
 for prec in bf16 bf16x3 fp16x2; do
   for v in r3lib nofold fold; do
     case $v in
