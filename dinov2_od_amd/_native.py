@@ -113,6 +113,7 @@ SYMBOLS = {
     "dod_op_quant_mx_fp8": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "dod_op_linear_fp8_glu_mx": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "dod_op_linear_fp8_mx": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "dod_op_linear_fp8_mx2": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P]),
     "dod_op_split_pair": (_I, [_P, _I, _I, _I, _P, _P]),
     "dod_op_linear_x3": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "dod_op_attention_x3": (_I, [_P, _P, _I, _I, _I, _F, _P]),

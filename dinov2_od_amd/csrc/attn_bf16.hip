@@ -168,9 +168,11 @@ __device__ unsigned long long* g_attn_stamps = nullptr;
 // compile-time-constant LDS locations (a pointer parameter cost the 64-rows-per-wave body three registers and a spill)
 __shared__ __attribute__((aligned(16))) char g_attn_smem[3 * 2 * AT_KV * 128];
 // the kernel body for workgroup index `blk_` of a launch over query rows [q_lo, q_hi)
-template <int AT_NQ>
+// MX (fp8 mode, round 4): the context leaves as block-scaled e4m3 -- ctx is then a BYTE buffer [B*N, D], bs its e8m0 bytes [B*N][2][D / 64] --
+// the out-proj GEMM's operand, written here instead of by a quantisation pass over bf16 rows (a head's 64 columns are two blocks of 32)
+template <int AT_NQ, bool MX = false>
 __device__ __forceinline__ void attn_bf16_body(const int blk_, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                               int N, int heads, int npairs, float scale_log2e, int q_lo, int q_hi) {
+                                               int N, int heads, int npairs, float scale_log2e, int q_lo, int q_hi, unsigned char* __restrict__ bs = nullptr) {
   char* const smem = g_attn_smem;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -287,7 +289,26 @@ __device__ __forceinline__ void attn_bf16_body(const int blk_, const bf16_t* __r
     const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0 + qi * 32 + lr;
-    if (active && q < q_hi) {
+    if (MX) {
+      // block db of this head = columns db*32 .. +31 of query q: 16 of them in this lane, 16 in lane ^ 32 (every lane takes part in the shuffle)
+      const bool okq = active && q < q_hi;
+      unsigned char* op8 = reinterpret_cast<unsigned char*>(ctx) + ((size_t)b * N + q) * D + h * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        float amax = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(o[qi][db][r] * inv));
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const unsigned eb = mx_ebyte(amax);
+        const float sc = inv * mx_inv_scale(eb);
+        if (okq) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<unsigned*>(op8 + db * 32 + 8 * g + 4 * lh) = pack4_fp8(o[qi][db][4 * g] * sc, o[qi][db][4 * g + 1] * sc, o[qi][db][4 * g + 2] * sc, o[qi][db][4 * g + 3] * sc);
+          if (lh == 0) bs[((size_t)b * N + q) * (D >> 5) + mx_scale_off(D, h * 2 + db)] = (unsigned char)eb;
+        }
+      }
+    } else if (active && q < q_hi) {
       bf16_t* op = ctx + ((size_t)b * N + q) * D + h * 64;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -302,19 +323,20 @@ __device__ __forceinline__ void attn_bf16_body(const int blk_, const bf16_t* __r
   }
 }
 
-template <int AT_NQ>
+template <int AT_NQ, bool MX>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                        int N, int heads, int npairs, float scale_log2e, int q_lo, int q_hi) {
-  attn_bf16_body<AT_NQ>(blockIdx.x, qkv, ctx, N, heads, npairs, scale_log2e, q_lo, q_hi);
+                                                        int N, int heads, int npairs, float scale_log2e, int q_lo, int q_hi, unsigned char* __restrict__ bs) {
+  attn_bf16_body<AT_NQ, MX>(blockIdx.x, qkv, ctx, N, heads, npairs, scale_log2e, q_lo, q_hi, bs);
 }
 // ONE launch for a sequence whose last 256-row block is short (N = 1370: 5 blocks + 90 rows): workgroups [0, main_blocks) run the
 // 64-rows-per-wave body over rows [0, q_main), the workgroups behind them the 32-rows-per-wave body over the remainder -- dispatched
 // last, they fill the main part's end-of-kernel bubble instead of costing a launch of their own (round 3: the separate tail launch
 // took 62.6 us per layer for 6.6 % of the rows, profiles/r03_bench_bf16_kernel_stats.csv).  main_blocks % 8 == 0 keeps both XCD maps.
+template <bool MX>
 __global__ __launch_bounds__(256, 2) void attn_bf16_fused_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                              int N, int heads, int npairs, float scale_log2e, int main_blocks, int q_main) {
-  if ((int)blockIdx.x < main_blocks) attn_bf16_body<2>(blockIdx.x, qkv, ctx, N, heads, npairs, scale_log2e, 0, q_main);
-  else attn_bf16_body<1>((int)blockIdx.x - main_blocks, qkv, ctx, N, heads, npairs, scale_log2e, q_main, N);
+                                                              int N, int heads, int npairs, float scale_log2e, int main_blocks, int q_main, unsigned char* __restrict__ bs) {
+  if ((int)blockIdx.x < main_blocks) attn_bf16_body<2, MX>(blockIdx.x, qkv, ctx, N, heads, npairs, scale_log2e, 0, q_main, bs);
+  else attn_bf16_body<1, MX>((int)blockIdx.x - main_blocks, qkv, ctx, N, heads, npairs, scale_log2e, q_main, N, bs);
 }
 
 #ifdef DINODET_TUNING
@@ -324,8 +346,10 @@ extern "C" int dod_debug_attn_stamps(void* dev_buf) {
 }
 #endif
 
-int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s) {
+int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s, unsigned char* ctx_bs) {
   if (B <= 0 || N <= 0 || heads <= 0) return 1;
+  if (ctx_bs && (heads * 64) % 64 != 0) return 2;
+  const bool mx = ctx_bs != nullptr;
   const int npairs = B * heads, pairs8 = (npairs + 7) / 8 * 8;
   const float c = scale * 1.44269504088896340736f;
   // 64 query rows per wave once the grid still fills the chip several times over (measured: +5 % at B*heads = 768,
@@ -342,14 +366,21 @@ int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, fl
     const int nqb = (q_main + AT_WAVES * 64 - 1) / (AT_WAVES * 64);
     static const char* fse = DOD_TUNE_ENV("DINODET_ATTN_FUSED_TAIL");      // "0": the two-launch form (A/B)
     if (split && !(fse && fse[0] == '0')) {
-      hipLaunchKernelGGL(attn_bf16_fused_kernel, dim3(pairs8 * nqb + pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, pairs8 * nqb, q_main);
+      if (mx) hipLaunchKernelGGL(attn_bf16_fused_kernel<true>, dim3(pairs8 * nqb + pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, pairs8 * nqb, q_main, ctx_bs);
+      else hipLaunchKernelGGL(attn_bf16_fused_kernel<false>, dim3(pairs8 * nqb + pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, pairs8 * nqb, q_main, ctx_bs);
     } else {
-      hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, 0, q_main);
-      if (split) hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, q_main, N);
+      if (mx) {
+        hipLaunchKernelGGL((attn_bf16_kernel<2, true>), dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, 0, q_main, ctx_bs);
+        if (split) hipLaunchKernelGGL((attn_bf16_kernel<1, true>), dim3(pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, q_main, N, ctx_bs);
+      } else {
+        hipLaunchKernelGGL((attn_bf16_kernel<2, false>), dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, 0, q_main, ctx_bs);
+        if (split) hipLaunchKernelGGL((attn_bf16_kernel<1, false>), dim3(pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, q_main, N, ctx_bs);
+      }
     }
   } else {
     const int nqb = (N + AT_WAVES * 32 - 1) / (AT_WAVES * 32);
-    hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, 0, N);
+    if (mx) hipLaunchKernelGGL((attn_bf16_kernel<1, true>), dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, 0, N, ctx_bs);
+    else hipLaunchKernelGGL((attn_bf16_kernel<1, false>), dim3(pairs8 * nqb), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, 0, N, ctx_bs);
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

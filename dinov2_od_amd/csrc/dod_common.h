@@ -157,6 +157,7 @@ struct GemmEpi {
   const float* w_scale;   // fp8 GEMM only: per-output-feature dequant scale of W, [N]
   unsigned char* out_bs;       // fp8 GEMM with glu only: the gated rows leave as e4m3 (out_bf16 = byte rows, pitch ldc bytes) with these e8m0 block scales [M][2][F / 64]
   const unsigned char* a_bs;   // fp8 GEMM only: e8m0 BLOCK scales of A (one byte per 32 elements along K, layout [M][2][K / 64]: gemm_fp8.hip) instead of a_scale
+  const unsigned char* w_bs;   // fp8 GEMM with a_bs only: e8m0 block scales of W in the same layout [N][2][K / 64] instead of w_scale
   int out_h2;             // with out_bf16: H2 activation rows (above) of N columns at row pitch ldc (2-byte units, >= 2N)
   const unsigned char* h2_wexp;   // H2 GEMM only: E8M0 byte (127 - e) of every weight row's e4m3 scale 2^e, [N]
   int ksplit;             // ping-pong / H2 kernels only: > 1 = the grid's y index is a K slice of kslice_len k; the slice's fp32 partial
@@ -226,7 +227,8 @@ int launch_quant_rows_fp8(const void* x, int in_bf16, int ld, int rows, int cols
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s,
                      unsigned char* out_fp8 = nullptr, float* out_scale = nullptr, bf16_t* out_split3 = nullptr, int h2 = 0,
-                     bf16_t* out_a3 = nullptr);      // out_a3 (with out_f32 only): also the bf16x3 activation layout [hi | hi | lo], row pitch 3*D
+                     bf16_t* out_a3 = nullptr,       // out_a3 (with out_f32 only): also the bf16x3 activation layout [hi | hi | lo], row pitch 3*D
+                     unsigned char* out_bs = nullptr);   // with out_fp8 (and no out_scale): block-scaled e4m3 rows, e8m0 bytes [rows][2][D / 64]
 // ---- folded LayerNorm (GemmEpi::ln_*): row statistics only.
 // rows of x -> operand copy of x ITSELF (kind LNOP_*, as GemmEpi::ln_op) + (mean, rstd) per row: what the first block's QKV needs (its
 // producer is the patch embedding, not a residual GEMM)
@@ -240,7 +242,8 @@ int launch_ln_fold(const float* W, int rows, int cols, const float* gamma, const
 int launch_rowsum(const float* W, int rows, int cols, int round_bf16, float* c, hipStream_t s);
 
 // backbone attention, bf16 MFMA flash kernel, head_dim 64.  qkv [B*N, 3*D] bf16 -> ctx [B*N, D] bf16
-int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s);
+// ctx_bs != null (fp8 mode): ctx is a BYTE buffer of block-scaled e4m3 rows [B*N, D], ctx_bs its e8m0 bytes [B*N][2][D / 64]
+int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, float scale, hipStream_t s, unsigned char* ctx_bs = nullptr);
 
 // generic fp32 attention (strict backbone, decoder self-attn, dense cross-attn). head_dim <= 128, %4 == 0
 struct AttnF32 {

@@ -239,7 +239,7 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
   const int c4 = tid % C4;
   const int n = n0 + 4 * c4;
   if (n >= N && LN != LN_PROD) return;
-  if (e.resid && e.out_f32 && e.rows_per_img == 0 && !e.a_scale && !e.a_bs) {
+  if (e.resid && e.out_f32 && e.rows_per_img == 0 && !e.a_scale && (!e.a_bs || e.w_bs)) {      // (fp8 with BOTH operands block-scaled: nothing left to dequantise here)
     // The in-place fp32 residual epilogue (out-proj, fc2): a thread visits ROWS / (NT / C4) rows, and with one residual load in flight
     // per thread the pass is a chain of memory latencies (tools/pp_timeline.py: 63 k cycles per 256x256 tile, 15 GB/s per CU).
     // Rows go in batches of RB: RB residual loads are issued before the first of them is consumed.  (Unrolling the whole generic loop

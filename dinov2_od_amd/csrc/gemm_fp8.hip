@@ -184,7 +184,13 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8_256x128_kernel(const unsigned
 // any byte order both operands share is a dot product): chunks 0, 1 -- the row's first 32 elements -- are then the instruction's block 0.
 // vmcnt per wave and K-tile: 3 ring pieces, plus the scale piece of the NEXT group issued in the first iteration of a group; at the top of
 // iteration kt everything issued in iteration kt - 1 may still fly: 3, or 4 when kt - 1 opened a group that has a successor.
+// WBS (round 4): W block-scaled too (GemmEpi::w_bs, the same [rows][2][K / 64] layout: quant_mx_fp8_kernel packs the weights): its 128 rows
+// x 2 halves are 256 scale dwords per group of four K-tiles -- every wave issues one more 4-byte-per-lane LDS-DMA per group (waves 4..7
+// repeat waves 0..3: the same bytes to the same LDS words, so that every wave's vmcnt counts the same pieces) -- and the weight fragment's scale
+// operand takes this K-tile's byte instead of the constant 2^0.
 #define F8_SC_BYTES 2048
+#define F8_SCW_BYTES 1024
+template <bool WBS>
 __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsigned char* __restrict__ A, int lda,
                                                                     const unsigned char* __restrict__ W, int ldw,
                                                                     int M, int N, int K, GemmEpi e, int GM) {
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
   const int m0 = tm * F8M, n0 = tn * F8N;
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  const unsigned char* gA0; const unsigned char* gA1; const unsigned char* gW0; const unsigned char* gS;
+  const unsigned char* gA0; const unsigned char* gA1; const unsigned char* gW0; const unsigned char* gS; const unsigned char* gSW = nullptr;
   {
     auto src = [&](const unsigned char* base, int ld, int r0, int piece, int lim) {
       const int rl = piece * 16 + (lane >> 2);
@@ -223,6 +229,11 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
     const int sidx = wid * 64 + lane;
     int r = m0 + (sidx >> 1); r = r < M ? r : M - 1;
     gS = e.a_bs + (size_t)r * (K >> 5) + (size_t)(sidx & 1) * (K >> 6);
+    if (WBS) {
+      const int sw = (wid & 3) * 64 + lane;
+      int rw = n0 + (sw >> 1); rw = rw < N ? rw : N - 1;
+      gSW = e.w_bs + (size_t)rw * (K >> 5) + (size_t)(sw & 1) * (K >> 6);
+    }
   }
   const int wu = __builtin_amdgcn_readfirstlane(wid);
   char* const sc_base = smem + F8_SLOTS * F8_STAGE;                   // two 2-KiB scale buffers behind the ring
@@ -234,7 +245,11 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
     __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (k0)), (lptr_t)(sA_ + 1024), 16, 0, 0);                \
     __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sW_), 16, 0, 0);                       \
   }
-#define STAGE8S(g_) __builtin_amdgcn_global_load_lds((gptr_t)(gS + 4 * (g_)), (lptr_t)(sc_base + ((g_) & 1) * F8_SC_BYTES + wu * 256), 4, 0, 0);
+#define STAGE8S(g_)                                                                                                                            \
+  {                                                                                                                                            \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gS + 4 * (g_)), (lptr_t)(sc_base + ((g_) & 1) * F8_SC_BYTES + wu * 256), 4, 0, 0);               \
+    if (WBS) __builtin_amdgcn_global_load_lds((gptr_t)(gSW + 4 * (g_)), (lptr_t)(sc_base + 2 * F8_SC_BYTES + ((g_) & 1) * F8_SCW_BYTES + (wu & 3) * 256), 4, 0, 0); \
+  }
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
   STAGE8S(0)
   STAGE8M(0, 0)
   STAGE8M(1, F8K)                      // nk >= 4
-  int offA[2], offW[2], offS[2];
+  int offA[2], offW[2], offS[2], offSW[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = wm * 64 + i * 32 + lr;
@@ -255,15 +270,15 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
     offS[i] = (row * 2 + lh) * 4;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offW[j] = F8M * F8K + row * 64 + swz64(row, lh) * 16; }
+  for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offW[j] = F8M * F8K + row * 64 + swz64(row, lh) * 16; offSW[j] = (row * 2 + lh) * 4; }
   int slot = 0;
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  int sca[2] = {0, 0};
+  int sca[2] = {0, 0}, scw[2] = {0x7f7f7f7f, 0x7f7f7f7f};
   for (int kt = 0; kt < nk; ++kt) {
     const int u = kt & 3, g = kt >> 2;                 // wave-uniform
     const bool has_next = g + 1 < ng;
     if (kt + 1 < nk) {
-      if (u == 1 && has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (u == 1 && has_next) { if (WBS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -277,6 +292,10 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
     if (u == 0) {       // this group's scale dwords (read as ushort pairs: an int-typed read "may alias" the pending LDS-DMA writes)
 #pragma unroll
       for (int i = 0; i < 2; ++i) sca[i] = __builtin_bit_cast(int, *reinterpret_cast<const us2*>(sc_base + (g & 1) * F8_SC_BYTES + offS[i]));
+      if (WBS) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) scw[j] = __builtin_bit_cast(int, *reinterpret_cast<const us2*>(sc_base + 2 * F8_SC_BYTES + (g & 1) * F8_SCW_BYTES + offSW[j]));
+      }
     }
     i32x8 af[2], wf[2];
 #pragma unroll
@@ -295,8 +314,8 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
     for (int i = 0; i < 2; ++i) {
       const int sb = (int)((unsigned)sca[i] >> (8 * u));      // this K-tile's byte into byte 0 (op_sel 0)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)   // W: constant block scale 2^0 (byte 127)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 127, 0, sb);
+      for (int j = 0; j < 2; ++j)   // W: its block's byte, or the constant block scale 2^0 (byte 127)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, WBS ? (int)((unsigned)scw[j] >> (8 * u)) : 127, 0, sb);
     }
     slot = slot == 2 ? 0 : slot + 1;
   }
@@ -312,12 +331,13 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
     for (int j = 0; j < 2; ++j)
       stage_acc(smem, PITCH, wm * 32 + lr, wn * 64 + j * 32, acc[pass][j], lh);
     __syncthreads();
-    drain_tile<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                              [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+    if (e.out_bs) drain_glu_mx<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+    else drain_tile<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
+                                   [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
   }
 }
 
-static constexpr int LDS8MX = F8_SLOTS * F8_STAGE + 2 * F8_SC_BYTES;
+static constexpr int LDS8MX = F8_SLOTS * F8_STAGE + 2 * F8_SC_BYTES + 2 * F8_SCW_BYTES;
 static constexpr int LDS8 = (128 * (F8N * 4 + 16)) > F8_SLOTS * F8_STAGE ? (128 * (F8N * 4 + 16)) : F8_SLOTS * F8_STAGE;
 
 static void fp8_attr() {      // > 64 KiB of dynamic LDS: once per DEVICE (a process may drive several)
@@ -326,7 +346,8 @@ static void fp8_attr() {      // > 64 KiB of dynamic LDS: once per DEVICE (a pro
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8MX);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8MX);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8MX);
     attr_set[dev] = true;
   }
 }
@@ -338,15 +359,16 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
-  if (!e.w_scale || (!e.a_scale && !e.a_bs)) return 2;
+  if ((!e.w_scale && !e.w_bs) || (!e.a_scale && !e.a_bs) || (e.w_bs && !e.a_bs)) return 2;
   if (e.out_bs && (!e.glu || !e.out_bf16 || N % 128 != 0 || e.scale || e.resid || e.act != ACT_NONE)) return 2;
   if (e.a_bs) {          // block-scaled activations
     if (K % 256 != 0) return 2;
-    if (reinterpret_cast<uintptr_t>(e.a_bs) & 3) return 2;      // the scale bytes arrive by 4-byte LDS-DMA
+    if ((reinterpret_cast<uintptr_t>(e.a_bs) | reinterpret_cast<uintptr_t>(e.w_bs)) & 3) return 2;      // the scale bytes arrive by 4-byte LDS-DMA
     fp8_attr();
     const int gm = N >= 3072 ? 8 : (N >= 2048 ? 4 : 2);
     const int tiles = ((M + F8M - 1) / F8M) * ((N + F8N - 1) / F8N);
-    hipLaunchKernelGGL(gemm_fp8mx_256x128_kernel, dim3(tiles), dim3(512), LDS8MX, s, A, lda, W, ldw, M, N, K, e, gm);
+    if (e.w_bs) hipLaunchKernelGGL(gemm_fp8mx_256x128_kernel<true>, dim3(tiles), dim3(512), LDS8MX, s, A, lda, W, ldw, M, N, K, e, gm);
+    else hipLaunchKernelGGL(gemm_fp8mx_256x128_kernel<false>, dim3(tiles), dim3(512), LDS8MX, s, A, lda, W, ldw, M, N, K, e, gm);
     return hipGetLastError() == hipSuccess ? 0 : 3;
   }
   fp8_attr();

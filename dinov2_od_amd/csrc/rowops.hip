@@ -11,8 +11,8 @@
 #define LN_MAXC 8
 // Output forms (compile-time: the round-2 kernel took them as runtime pointers / an int and carried every writer's registers -- 100
 // VGPRs, four waves per SIMD -- which cost 27 % of its bandwidth).
-enum { LN_F32 = 1, LN_BF16 = 2, LN_PAIR = 4, LN_H2 = 8, LN_FP8 = 16, LN_S3 = 32 };
-struct LnOut { float* f32; bf16_t* bf16; unsigned char* fp8; float* scale; bf16_t* split; bf16_t* a3; };
+enum { LN_F32 = 1, LN_BF16 = 2, LN_PAIR = 4, LN_H2 = 8, LN_FP8 = 16, LN_S3 = 32, LN_FP8MX = 64 };
+struct LnOut { float* f32; bf16_t* bf16; unsigned char* fp8; float* scale; bf16_t* split; bf16_t* a3; unsigned char* bs; };
 // NCH float4 chunks per lane (compile-time trip count: D = 768 holds a row in 3 x 4 registers instead of LN_MAXC x 4); EXACT: D == 256 NCH
 template <int NCH, bool EXACT, int OUT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
@@ -65,6 +65,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       v[i].z = (v[i].z - mean) * rstd * g.z + b.z;
       v[i].w = (v[i].w - mean) * rstd * g.w + b.w;
     }
+  }
+  if (OUT & LN_FP8MX) {   // block-scaled e4m3 operand (dod_common.h mx_ebyte): one e8m0 byte per 32 columns = 8 consecutive lanes' float4s
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = EXACT || c < nc;
+      float amax = ok ? fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))) : 0.f;
+      amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+      const unsigned eb = mx_ebyte(amax);
+      const float inv = mx_inv_scale(eb);
+      if (ok) {
+        reinterpret_cast<unsigned*>(o.fp8 + (size_t)row * D)[c] = pack4_fp8(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+        if ((lane & 7) == 0) o.bs[(size_t)row * (D >> 5) + mx_scale_off(D, c >> 3)] = (unsigned char)eb;
+      }
+    }
+    return;
   }
   if (OUT & LN_FP8) {   // fp8 operand for the next GEMM: normalised row kept in registers, one scale per row (amax / 448)
     float amax = 0.f;
@@ -156,12 +174,18 @@ static void ln_dispatch(const float* x, const float* add, const float* gamma, co
 
 int launch_layernorm(const float* x, const float* add, const float* gamma, const float* beta, float eps,
                      int rows, int D, float* out_f32, bf16_t* out_bf16, hipStream_t s, unsigned char* out_fp8,
-                     float* out_scale, bf16_t* out_split3, int h2, bf16_t* out_a3) {
+                     float* out_scale, bf16_t* out_split3, int h2, bf16_t* out_a3, unsigned char* out_bs) {
   if (rows <= 0) return 1;
   if (D % 4 != 0 || D > 256 * LN_MAXC) return 2;
   if (h2 && (!out_split3 || D % 32 != 0)) return 2;
+  if (out_bs) {        // block-scaled e4m3 rows: out_fp8 + one e8m0 byte per 32 columns (layout [rows][2][D / 64])
+    if (!out_fp8 || out_scale || out_f32 || out_bf16 || out_split3 || out_a3 || D % 64 != 0) return 2;
+    LnOut o{nullptr, nullptr, out_fp8, nullptr, nullptr, nullptr, out_bs};
+    ln_dispatch<LN_FP8MX>(x, add, gamma, beta, eps, rows, D, o, s);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+  }
   if ((out_fp8 == nullptr) != (out_scale == nullptr)) return 2;
-  LnOut o{out_f32, out_bf16, out_fp8, out_scale, out_split3, out_a3};
+  LnOut o{out_f32, out_bf16, out_fp8, out_scale, out_split3, out_a3, nullptr};
   if (out_a3) {
     if (!out_f32 || out_bf16 || out_fp8 || out_split3) return 2;
     ln_dispatch<LN_F32 | LN_S3>(x, add, gamma, beta, eps, rows, D, o, s);

@@ -188,6 +188,12 @@ int dod_op_linear_fp8_mx(const void* A, int lda, const void* a_block_scales, con
  * e8m0 bytes in out_block_scales in the dod_op_quant_mx_fp8 layout -- the A operand of dod_op_linear_fp8_mx. */
 int dod_op_linear_fp8_glu_mx(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale,
                              int M, int N, int K, const float* bias, void* out_q, int ldq, void* out_block_scales, void* stream);
+/* Both operands block-scaled (what the fp8 mode's linears run since round 4): W [N, K] e4m3 with e8m0 bytes in the same [N][2][K / 64] layout
+ * (dod_op_quant_mx_fp8 on the weight matrix).  glu_out_block_scales != NULL: the weights_in form of dod_op_linear_fp8_glu_mx (out = e4m3 rows
+ * of N / 2 gated columns at pitch ldc bytes, out_dtype DOD_BF16 as a byte buffer). */
+int dod_op_linear_fp8_mx2(const void* A, int lda, const void* a_block_scales, const void* W, int ldw, const void* w_block_scales,
+                          int M, int N, int K, const float* bias, const float* scale, const float* resid, int ldr,
+                          void* out, int out_dtype, int ldc, int act, void* glu_out_block_scales, void* stream);
 /* bf16x3 (parity-gated mode) operators.  Pair layout: [rows, 2*cols] bf16 = [hi | lo], hi = bf16(x), lo = bf16(x - hi).
  * dod_op_split_pair: fp32 x [rows, cols] (ld) -> pair layout.
  * dod_op_linear_x3: A2 [M, 2K], W2 [N, 2K] pair layouts -> act(A W^T + bias) * scale + resid as the split product

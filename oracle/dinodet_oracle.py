@@ -28,7 +28,7 @@ tell which of two fp32 implementations is closer to the exact result).
 `emulate_bf16=True` rounds GEMM/attention operands to bf16 at the points where the
 HIP fast path does (DESIGN.md "precision modes"); accumulation stays fp32.
 `emulate_bf16="fp8"` additionally fake-quantises the operands of the linears the fp8 mode
-runs on e4m3 MFMA (per-token / per-output-feature scales, torch.float8_e4m3fn rounding).
+runs on e4m3 MFMA (block scales: one power of two per 32 elements along K on both operands; torch.float8_e4m3fn rounding).
 `emulate_bf16="fp16x2"` evaluates the four linears of every backbone block with the H2 operand scheme of the fp16x2 mode
 (dinov2_od_amd/csrc/dod_common.h: x = h + l, h = fp16(x); x.w ~ h_x h_w + e4m3(h_x) e4m3(l_w 2^(e+11)) 2^-(e+11)
 + e4m3(l_x 2^11) e4m3(h_w 2^e) 2^-(e+11), e the weight row's power-of-two scale) and everything else exactly: the scheme's own
@@ -132,8 +132,10 @@ def _linear(x, w, b, emu, fp8=False):
         y = _h2_product(x, w)
         return y if b is None else y + b
     if emu and fp8:
-        # per-token activation scales, per-output-feature weight scales; fp8 == "w": the activation arrives already quantised (block-scaled)
-        x, w = (x if fp8 == "w" else _q8(x)), _q8(w)
+        # round 4: BOTH operands block-scaled (one power-of-two scale per 32 elements along K: _q8_mx) wherever the HIP path can (K % 256 == 0);
+        # other widths keep per-token activation scales / per-output-feature weight scales.  fp8 == "w": the activation arrives already quantised
+        q = _q8_mx if x.shape[-1] % 256 == 0 else _q8
+        x, w = (x if fp8 == "w" else q(x)), q(w)
     elif emu:
         x, w = _bf(x), _bf(w)
     y = x @ w.t()
@@ -296,8 +298,9 @@ def backbone_forward(sd_raw, bb: BackboneConfig, pixel_values, dtype=torch.float
         else:
             ctx = torch.softmax(s, dim=-1) @ v
         ctx = ctx.transpose(1, 2).reshape(B, N, D)
-        if emu == "fp8":
-            ctx = _bf(ctx)            # the fp8 path stores the context in bf16, then quantises its rows
+        if emu == "fp8" and D % 256 != 0:
+            ctx = _bf(ctx)            # widths without block scales: the fp8 path stores the context in bf16, then quantises its rows
+                                      # (block-scaled: the attention epilogue quantises its fp32 tile directly)
         o = _maybe_lora_linear(sd, lp + "attention.output.dense", ctx, a, emu_lin, emu == "fp8")
         h = o * sd(lp + "layer_scale1.lambda1") + h
         if taps is not None and i == 0:

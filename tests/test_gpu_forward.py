@@ -614,6 +614,15 @@ def test_full_depth_configs_throughput_modes(G, variant, precision):
         got, floor = rel_l2(r[k], g[gk]), rel_l2(emu[ek], g[gk])
         print(f"{variant} {precision} {k}: rel-L2 vs the reference {got:.2e} (faithful oracle {floor:.2e})")
         assert np.isfinite(r[k]).all() and got < K * floor, (k, got, floor)
+    if precision == "fp8":
+        # The fp8 mode's own accuracy criterion against the REFERENCE (golden G8), not against an emulation of itself: the class with the
+        # highest logit agrees for >= 99 % of the 300 queries and the logits stay within 1.5e-1 rel-L2.  (Round 3, per-row / per-feature
+        # scales: 96.3 % / 1.6e-1; block scales on both operands: 99.3 % / 1.4e-1.  5e-2 is out of reach of ANY use of e4m3 operands in
+        # every block: the oracle puts a model with e4m3 on weights_in alone at 9.1e-2, on QKV alone at 1.2e-1 -- DESIGN section 2.)
+        top1 = float((r["pred_logits"].argmax(-1) == g["pred_logits"].argmax(-1)).mean())
+        l2 = rel_l2(r["pred_logits"], g["pred_logits"])
+        print(f"{variant} fp8 vs the reference: top-1 class agreement {top1:.4f}, logits rel-L2 {l2:.3e}, boxes rel-L2 {rel_l2(r['pred_boxes'], g['pred_boxes']):.3e}")
+        assert top1 >= 0.99 and l2 <= 1.5e-1
 
 
 _SWEEP_ORACLE = {}

@@ -154,6 +154,43 @@ def test_linear_fp8_mx_block_scaled_activations(M, N, K):
     assert e_mx < 1.1 * e_row
 
 
+@pytest.mark.parametrize("M,N,K", [(515, 384, 1536), (4110 + 7, 1536, 4096), (300, 128, 256), (2740, 4608, 1536)])
+def test_linear_fp8_mx_both_operands_block_scaled(M, N, K):
+    """round 4: W block-scaled too (one e8m0 byte per 32 k on BOTH operands of v_mfma_scale_f32_32x32x64_f8f6f4): against the exact products
+    of the same operands; blocks of very different magnitude along K in rows of A and of W -- a block / scale-byte mix-up on either side
+    is off by orders of magnitude"""
+    L = nat.lib()
+    A = torch.from_numpy(_n(f"mx2.A.{M}.{K}", (M, K)))
+    A[:, : K // 2] *= 40.0
+    A[1::3] *= 1e-2
+    W = torch.from_numpy(_n(f"mx2.W.{N}.{K}", (N, K), 0.05))
+    W[:, K // 4: K // 2] *= 25.0                   # weight blocks of very different magnitude inside every row
+    W[2::5, :64] *= 1e-3
+    qa, lay_a, sca = mx_ref(A)
+    qw, lay_w, scw = mx_ref(W)
+    a_deq = (qa.float().reshape(M, K // 32, 32) * sca[..., None]).reshape(M, K).double()
+    w_deq = (qw.float().reshape(N, K // 32, 32) * scw[..., None]).reshape(N, K).double()
+    ref = a_deq @ w_deq.t()
+    bias, scale, resid = torch.from_numpy(_n("mx2.b", (N,))), 1 + torch.from_numpy(_n("mx2.s", (N,), 0.1)), torch.from_numpy(_n("mx2.r", (M, N)))
+    qa_d, ba_d, qw_d, bw_d = qa.view(torch.uint8).cuda(), lay_a.cuda(), qw.view(torch.uint8).cuda(), lay_w.cuda()
+
+    def run(bias=None, scale=None, resid=None, act="none", out_dtype=torch.float32):
+        out = torch.empty(M, N, dtype=out_dtype, device="cuda")
+        nat.check(L.dod_op_linear_fp8_mx2(nat.ptr(qa_d), K, nat.ptr(ba_d), nat.ptr(qw_d), K, nat.ptr(bw_d), M, N, K, nat.ptr(bias), nat.ptr(scale),
+                                          nat.ptr(resid), N if resid is not None else 0, nat.ptr(out),
+                                          nat.DOD_BF16 if out_dtype == torch.bfloat16 else nat.DOD_F32, N, nat.ACT[act], None, nat.stream_ptr()))
+        return out
+
+    err = rel_err(run().cpu().numpy(), ref.numpy())
+    print(f"fp8 mx/mx gemm M={M} N={N} K={K}: rel err vs exact products {err:.2e}")
+    assert err < ACC_TOL
+    want = (ref + bias.double()) * scale.double() + resid.double()
+    assert rel_err(run(bias.cuda(), scale.cuda(), resid.cuda()).cpu().numpy(), want.numpy()) < ACC_TOL
+    # the packer the forward uses for the weights (dod_op_quant_mx_fp8 on W) produces exactly these bytes
+    qg, bg = mx_gpu(W.cuda())
+    assert torch.equal(qg.cpu(), qw.view(torch.uint8)) and torch.equal(bg.cpu(), lay_w)
+
+
 @pytest.mark.parametrize("M,F,K", [(515, 256, 256), (1000 + 3, 4096, 1536)])
 def test_linear_fp8_glu_epilogue_quantises_block_scaled(M, F, K):
     """weights_in of the fp8 SwiGLU MLP: gate and block-scaled quantisation in the GEMM epilogue.  The dequantised output against
