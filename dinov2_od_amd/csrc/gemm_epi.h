@@ -330,7 +330,7 @@ __device__ __forceinline__ void drain_tile(const char* sm, int pitch, const Gemm
 // and row instead of two 8-byte ones: the store tail of a tile is bound by the number of store instructions, not by their bytes
 // (guide T21), and a workgroup per CU has nothing else to overlap it with.
 __device__ __forceinline__ bool drain8_ok(const GemmEpi& e, int N) {
-  return e.out_bf16 && e.out_split <= 0 && !e.resid && e.rows_per_img == 0 && !e.a_scale && !e.a_bs && (N & 7) == 0 && (e.ldc & 7) == 0 &&
+  return e.out_bf16 && e.out_split <= 0 && !e.resid && e.rows_per_img == 0 && !e.a_scale && (!e.a_bs || e.w_bs) && !e.out_bs && (N & 7) == 0 && (e.ldc & 7) == 0 &&
          (e.out_split == 0 || ((-e.out_split) & 7) == 0);
 }
 template <int ROWS, int COLS, int NT, int LN = LN_NONE, typename RowMap>

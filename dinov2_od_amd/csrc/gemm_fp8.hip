@@ -323,18 +323,23 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
 #undef STAGE8S
   constexpr int PITCH = F8N * 4 + 16;
   const ColParams cp = load_col_params<F8N>(e, n0, N, tid);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      stage_acc(smem, PITCH, wm * 32 + lr, wn * 64 + j * 32, acc[pass][j], lh);
-    __syncthreads();
-    if (e.out_bs) drain_glu_mx<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid, [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
-    else drain_tile<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid,
-                                   [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); });
+  const bool wide = drain8_ok(e, N);      // both operands block-scaled, bf16 output: nothing to dequantise -> 16-byte stores
+  // the two passes written out: as a `#pragma unroll` loop the body outgrows the unroller's threshold, acc[pass] becomes a scratch array
+  // and the kernel spills (104 bytes of scratch per lane); written out, every variant holds its accumulators in registers (0 spills)
+#define F8MX_PASS(P)                                                                                                           \
+  {                                                                                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                              \
+    asm volatile("" ::: "memory");                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) stage_acc(smem, PITCH, wm * 32 + lr, wn * 64 + j * 32, acc[P][j], lh);       \
+    auto rowmap = [&](int row_l) { return m0 + (row_l >> 5) * 64 + (P) * 32 + (row_l & 31); };                                 \
+    __syncthreads();                                                                                                           \
+    if (e.out_bs) drain_glu_mx<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);                                      \
+    else if (wide) drain_tile_bf16x8<128, F8N, 512>(smem, PITCH, e, M, N, n0, tid, rowmap);                                    \
+    else drain_tile<128, F8N, 512>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);                                                 \
   }
+  F8MX_PASS(0)
+  F8MX_PASS(1)
+#undef F8MX_PASS
 }
 
 static constexpr int LDS8MX = F8_SLOTS * F8_STAGE + 2 * F8_SC_BYTES + 2 * F8_SCW_BYTES;

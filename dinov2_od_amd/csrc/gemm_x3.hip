@@ -112,25 +112,27 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
   constexpr int PITCH = X3N * 4 + 16;
   const ColParams cp = load_col_params<X3N, LN>(e, n0, N, tid);
   const bool wide = drain8_ok(e, N);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row_l = wm * 32 + ii * 16 + l15;
-        const int col = wn * 64 + j * 16 + 4 * l4;
-        const f32x4 a = acc[pass * 2 + ii][j];
-        *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
-      }
-    auto rowmap = [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); };
-    stage_row_stats<128, X3N, LN>(smem, PITCH, e, M, tid, rowmap);
-    __syncthreads();
-    if (wide) drain_tile_bf16x8<128, X3N, 1024, LN>(smem, PITCH, e, M, N, n0, tid, rowmap);
-    else drain_tile<128, X3N, 1024, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);
+  // the two passes written out (as a `#pragma unroll` loop the body outgrows the unroller's threshold and the accumulators spill)
+#define X3_PASS(P)                                                                                                          \
+  {                                                                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                                           \
+    asm volatile("" ::: "memory");                                                                                          \
+    _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                                        \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                       \
+        const int row_l = wm * 32 + ii * 16 + l15;                                                                          \
+        const int col = wn * 64 + j * 16 + 4 * l4;                                                                          \
+        const f32x4 a = acc[(P) * 2 + ii][j];                                                                               \
+        *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);                   \
+      }                                                                                                                     \
+    auto rowmap = [&](int row_l) { return m0 + (row_l >> 5) * 64 + (P) * 32 + (row_l & 31); };                              \
+    stage_row_stats<128, X3N, LN>(smem, PITCH, e, M, tid, rowmap);                                                          \
+    __syncthreads();                                                                                                        \
+    if (wide) drain_tile_bf16x8<128, X3N, 1024, LN>(smem, PITCH, e, M, N, n0, tid, rowmap);                                 \
+    else drain_tile<128, X3N, 1024, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);                                         \
   }
+  X3_PASS(0)
+  X3_PASS(1)
+#undef X3_PASS
 }
 
 // tile-order mode of the 256x256 kernels (gemm_epi.h tile_map): group depth 4, time-ordered ("chunked") map.  Tuning builds: DINODET_GEMM_GM =
