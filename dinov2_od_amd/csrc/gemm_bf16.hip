@@ -318,8 +318,14 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
     const long tm = (M + 255) / 256, t_big = tm * ((N + 255) / 256), t_small = tm * ((N + 127) / 128);
     const double c_big = (double)((t_big + cu - 1) / cu) * (e.act == ACT_GELU ? 1.08 : 1.0);
     const double c_small = (double)((t_small + cu - 1) / cu) * (K >= 2048 ? 0.62 : 0.55);      // long K: the smaller tile's lower FLOP per staged byte shows
+    // Round 4: with its epilogue passes written out the 16-wave kernel holds its accumulators in registers (it had spilled 34 of them since
+    // round 1) and is the fastest choice for EVERY wide GEMM (N >= 1536: QKV, fc1 incl. its GELU epilogue) at every M measured
+    // (tools/bench_pp.py, rows 8 224 / 10 960 / 43 840 / 87 680: QKV 46.9 / 53.2 / 173.0 / 338.2 us against 51.8 / 56.8 / 186.6 / 345.5 for the
+    // round-3 choice, fc1 59.9 / 87.7 / 264.2 / 518.9 against 63.8 / 104.7 / 297.9 / 548.4); the narrow ones (N = 768) keep the round rule
+    // below, and the long-K narrow one (fc2) the ping-pong kernel behind its tail split.
+    if (N >= 1536 && K < 2048) return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
     if (c_big <= c_small * 1.02) {
-      if (N >= 1536) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
+      if (K >= 2048) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
       return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
     }
     LN_DISPATCH(e, GO_M16)

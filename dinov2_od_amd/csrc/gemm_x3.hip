@@ -183,7 +183,9 @@ int launch_gemm_x3(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, 
     // 512-thread epilogue: measured at M = 87680 against the 16-wave kernel below -- QKV 400 vs 378, fc1 376 vs 363, fc2 406 vs 371
     // TFLOP/s algorithmic; out-proj (N = K = 768) 276 vs 293, so that one stays.  (tuning builds: DINODET_X3_TILE = p / w forces either)
     const char* v = DOD_TUNE_ENV("DINODET_X3_TILE");
-    const bool pp = v ? v[0] == 'p' : (M >= 4096 && (N >= 1536 || K >= 2048));
+    // (round 4, after both kernels' epilogues were rewritten: the ping-pong kernel wins out-proj too -- 337.6 vs 345.1 us at M = 87 680,
+    // 183.0 vs 185.8 at 43 840, 58.0 vs 59.6 at 10 960 -- so every large-M split product takes it)
+    const bool pp = v ? v[0] == 'p' : (M >= 4096);
     if (pp) return launch_gemm_x3_pp(A2, lda, W2, ldw, M, N, K, e, s);
   }
   x3_attr();
