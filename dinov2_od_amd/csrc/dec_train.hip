@@ -1128,9 +1128,12 @@ struct TScratch { float *dx, *da, *db, *dbig, *dqkv, *dS, *Pd, *T, *U, *dump, *d
 // that the batched form is as fast (224x224: 10.0 vs 9.9 ms) and sits closer to a float64 evaluation -- the flash form takes
 // delta = <dO, O> from the forward's rounded output instead of sum_j P dP over the probabilities it multiplies (1.7e-5 vs 5.3e-5 from
 // float64 on the worst LoRA gradient at 1 370 tokens, the PyTorch composite 2.3e-5).  DINODET_ATTN_BWD_FLASH = 0 / 1 forces either.
+// This is the SINGLE predicate: the scratch carve (no dS / Pd when it holds), the forward's log-sum-exp tape and the backward all ask it, and it
+// contains everything launch_attn_f32_bwd itself checks (head_dim 64; q / k / v / o pitches 3D and D multiples of 4: D = heads * 64) -- so that
+// launcher's "not taken" return (2) cannot occur behind it; there is no second scratch layout to fall back to.
 inline bool tail_flash_bwd(const TDims& d) {
   static const char* e = getenv("DINODET_ATTN_BWD_FLASH");
-  if (d.dh != 64 || (e && e[0] == '0')) return false;
+  if (d.dh != 64 || d.D != d.H * 64 || d.D % 4 != 0 || d.B <= 0 || d.N <= 0 || (e && e[0] == '0')) return false;
   return (e && e[0] == '1') || d.N >= 1024;
 }
 size_t carve_tscratch(const TDims& d, void* base, TScratch* sc) {

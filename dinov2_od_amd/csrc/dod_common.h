@@ -260,7 +260,8 @@ struct AttnF32 {
 int launch_attn_f32(const AttnF32& a, hipStream_t s);
 // Adjoint of launch_attn_f32 without materialised scores (attn_f32m.hip; head_dim 64, exact-fp32 MFMA): q | k | v and their gradients
 // as strided [rows, ld] views like the forward's, o / d_o [B*Lq, ldo], lse from the forward, delta [B, heads, Lq] scratch.
-// Returns 2 when the shape is not taken (the caller keeps its batched-GEMM adjoint).
+// Returns 2 when the shape is not taken: callers decide BEFORE sizing their scratch (dec_train.hip tail_flash_bwd is the one predicate and
+// implies every check made here), so behind that predicate a 2 is a programming error, not a fallback.
 struct AttnF32Bwd {
   const float *q, *k, *v, *o, *d_o, *lse;
   float *dq, *dk, *dv, *delta;

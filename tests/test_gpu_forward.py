@@ -6,6 +6,8 @@ the CPU oracle, stage by stage.
 bf16 mode (the throughput mode) cannot meet 1e-3 on logits by construction (8-bit mantissa operands;
 DESIGN.md "precision modes"): it is held to the oracle evaluated with the same bf16 operand rounding,
 and its distance to the fp32 reference is bounded and reported."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -570,7 +572,12 @@ def _full_run(G, variant, precision):
 
 # (giant x fp16x2 at full depth is left to the two-block test above and to ViT-L at full depth: the -m gpu suite has a 900 s limit on the
 #  driver's box and the 40-block model costs 12-20 s per mode)
-@pytest.mark.parametrize("variant,precision", [("large", "fp32"), ("large", "bf16x3"), ("large", "fp16x2"), ("giant", "fp32"), ("giant", "bf16x3")])
+SLOW = pytest.mark.skipif(os.environ.get("DINODET_SLOW_TESTS") != "1", reason="40-block ViT-g in a third / fourth mode: outside the 900 s budget of "
+                          "the driver's -m gpu run; run once per round with DINODET_SLOW_TESTS=1 (DESIGN.md section 9 records the result)")
+
+
+@pytest.mark.parametrize("variant,precision", [("large", "fp32"), ("large", "bf16x3"), ("large", "fp16x2"), ("giant", "fp32"), ("giant", "bf16x3"),
+                                               pytest.param("giant", "fp16x2", marks=SLOW)])
 def test_full_depth_configs_gated_vs_reference(G, variant, precision):
     """configs[3] ViT-L/14 and configs[4] ViT-g/14 (SwiGLU, 40 blocks) at 518x518 with 300 queries, ALL blocks, one image:
     both parity-gated modes against the REFERENCE's own forward (G7 / G8: modeling_dinov2.py:300-314 at depth, the 1024 /
@@ -591,7 +598,7 @@ def test_full_depth_configs_gated_vs_reference(G, variant, precision):
         assert e < TOL, (k, e)
 
 
-@pytest.mark.parametrize("variant,precision", [("giant", "fp8"), ("large", "bf16")])   # giant is resident from the test above; each in the mode BASELINE quotes it in
+@pytest.mark.parametrize("variant,precision", [("giant", "fp8"), ("large", "bf16"), pytest.param("giant", "bf16", marks=SLOW)])   # giant is resident from the test above; each in the mode BASELINE quotes it in
 def test_full_depth_configs_throughput_modes(G, variant, precision):
     """The same two configurations in the opt-in throughput modes (configs[3] is quoted in bf16, configs[4] in fp8), full depth.
     Held (a) stage by stage to the oracle evaluated with the SAME operand rounding (tests/golden/emu_*.npz, generated by
