@@ -74,7 +74,8 @@ class DodBbTailParams(C.Structure):
 
 class DodLnFold(C.Structure):
     """struct dod_ln_fold (include/dinodet.h): the folded-LayerNorm legs of dod_op_linear_ln"""
-    _fields_ = [("stats", C.c_void_p), ("csum", C.c_void_p), ("op_out", C.c_void_p), ("part", C.c_void_p), ("shift", C.c_void_p)]
+    _fields_ = [("stats", C.c_void_p), ("csum", C.c_void_p), ("op_out", C.c_void_p), ("part", C.c_void_p), ("shift", C.c_void_p),
+                ("part_in", C.c_void_p), ("stats_out", C.c_void_p), ("eps", C.c_float)]
 
 
 # include/dinodet_tuning.h: exported by -DDINODET_TUNING builds only (tools/ load one through DINODET_LIB); bound when present

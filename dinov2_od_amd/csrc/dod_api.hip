@@ -69,6 +69,10 @@ struct dod_handle {
   bf16_t* bb0_w3 = nullptr;
   float *query = nullptr, *cls_w = nullptr, *cls_b = nullptr, *bb0_w = nullptr, *bb0_b = nullptr, *bb2_w = nullptr, *bb2_b = nullptr;
   int ncat = 0;
+  // Layer 0 of the decoder starts from tgt = query_embed for EVERY image (detr_decoder.py:59): its self-attention block and (deformable branch)
+  // its reference-point / offset / weight projections are functions of the weights alone -- computed once when the weights are packed, by the
+  // forward's own code path (decoder_impl, l0_only), and reused by every forward (five launches of ~25 us each on 2..72 workgroups otherwise)
+  float *l0_tgt = nullptr, *l0_proj = nullptr;
   // position-table cache
   // one table per distinct (H, W), kept until the next finalize / destroy: alternating input sizes neither leak nor
   // re-allocate, and hipGraphs captured for an earlier shape keep valid pointers
@@ -489,7 +493,7 @@ struct Carver {
   if ((size_t)((c).base - (char*)(workspace)) + (c).off > (wsb))                                                              \
     return fail(h, DOD_ERR_STATE, "internal: workspace carve %zu exceeds the %zu bytes provided", (size_t)((c).base - (char*)(workspace)) + (c).off, (size_t)(wsb));
 struct DecWS { float *tgt, *t2, *att, *samp, *qkv, *proj, *ffn, *hb, *qd; void* mem_op; float* values; float* kv; bf16_t* a3; bf16_t* a3b; bf16_t* mem2; };   // mem2: bf16x3 mode, memory in the pair layout [M, 2*Dd]
-struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; float* rs; unsigned char* bs; unsigned char* bsx; float2 *lnp, *lns; };   // bsx: fp8 mode, e8m0 block scales of the D-wide operand rows in ws.y   // rs: fp8 mode, per-row activation scales [M]; lnp / lns: folded LayerNorm group / row statistics
+struct BbWS { float* x; void *y, *qkv, *ctx, *hbuf, *gated, *mem; float* rs; unsigned char* bs; unsigned char* bsx; float2 *lnp, *lns, *lns2; };   // bsx: fp8 mode, e8m0 block scales of the D-wide operand rows in ws.y   // rs: fp8 mode, per-row activation scales [M]; lnp / lns: folded LayerNorm group / row statistics
 
 size_t carve_decoder(const dod_handle* h, Carver& c, int B, int N, DecWS* w, bool need_mem_op) {
   const dod_config& g = h->cfg;
@@ -533,6 +537,7 @@ size_t carve_backbone(const dod_handle* h, Carver& c, int B, int N, BbWS* w) {
   const bool foldable = !is_fp8(h) && (is_bf16(h) || is_x3(h)) && D % 32 == 0;      // (not "L.fold": the sizing pass may run before finalize)
   t.lnp = foldable ? (float2*)c.take(M * ((D + 127) / 128) * 8) : nullptr;
   t.lns = foldable ? (float2*)c.take(M * 8) : nullptr;
+  t.lns2 = foldable ? (float2*)c.take(M * 8) : nullptr;
   if (w) *w = t;
   return c.off;
 }
@@ -651,21 +656,31 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
   const int nblocks = stop_blocks >= 0 ? (stop_blocks < g.layers ? stop_blocks : g.layers) : g.layers;
   // Folded LayerNorm (BLayer::fold; modeling_dinov2.py:361-380): no norm1 / norm2 pass.  ws.y always holds the CURRENT residual rows in the
   // operand format (written by rowstats for block 0, then by the out-proj / fc2 epilogues), ws.lns their (mean, rstd).
-  const bool fold = !h->L.empty() && h->L[0].fold && ws.lnp && ws.lns;
+  const bool fold = !h->L.empty() && h->L[0].fold && ws.lnp && ws.lns && ws.lns2;
   const int op_kind = is_h2(h) ? LNOP_H2 : (x3 ? LNOP_PAIR : LNOP_BF16);
   const int npart = (D + 127) / 128;
+  // Row statistics ping-pong between two [M] buffers: stat[cur] holds the rows' latest (mean, rstd) -- the shift of the next producer; the consumer
+  // behind a producer reads that shift from stat[cur] with the producer's group sums, finishes the statistics in its epilogue and publishes them
+  // to stat[cur ^ 1] (its other tiles still read the shift): no launch merges the groups
+  float2* stat[2] = {ws.lns, ws.lns2};
+  int cur = 0;
+  bool fresh = false;      // a producer wrote group sums since the last consumer
   auto ln_producer = [&](GemmEpi e, bool wanted) {      // residual epilogue: + operand copy of the new rows + their group statistics
-    if (fold && wanted) { e.ln_op = ws.y; e.ln_op_kind = op_kind; e.ln_op_ld = (op_kind == LNOP_BF16 ? D : 2 * D); e.ln_part = ws.lnp; e.ln_npart = npart; e.ln_shift = ws.lns; }
+    if (fold && wanted) {
+      e.ln_op = ws.y; e.ln_op_kind = op_kind; e.ln_op_ld = (op_kind == LNOP_BF16 ? D : 2 * D); e.ln_part = ws.lnp; e.ln_npart = npart; e.ln_shift = stat[cur];
+      fresh = true;
+    }
     return e;
   };
-  auto ln_consumer = [&](GemmEpi e, const float* csum) { if (fold) { e.ln_stats = ws.lns; e.ln_c = csum; } return e; };
-  auto ln_merge = [&](bool wanted) -> int {
-    if (!fold || !wanted) return 0;
-    ProfScope ps(h, s, PC_LAYERNORM, 0);
-    KCHK(h, launch_ln_finalize(ws.lnp, npart, M, D, g.ln_eps, ws.lns, s));
-    return 0;
+  auto ln_consumer = [&](GemmEpi e, const float* csum) {
+    if (fold) {
+      e.ln_stats = stat[cur]; e.ln_c = csum;
+      if (fresh) { e.ln_part_in = ws.lnp; e.ln_npart = npart; e.ln_stats_out = stat[cur ^ 1]; e.ln_eps = g.ln_eps; cur ^= 1; fresh = false; }
+    }
+    return e;
   };
-  if (fold && nblocks > 0) { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_rowstats(ws.x, M, D, g.ln_eps, ws.y, op_kind, ws.lns, s)); }
+  auto ln_merge = [&](bool) -> int { return 0; };      // (rounds 4a: a finalize launch per LayerNorm; now the consumer's epilogue)
+  if (fold && nblocks > 0) { ProfScope ps(h, s, PC_LAYERNORM, 0); KCHK(h, launch_rowstats(ws.x, M, D, g.ln_eps, ws.y, op_kind, stat[0], s)); }
   for (int i = 0; i < nblocks; ++i) {
     const BLayer& L = h->L[i];
     const bool more = i + 1 < g.layers;      // another block reads the residual after this one (the final LayerNorm is a kernel of its own)
@@ -832,7 +847,8 @@ int backbone_impl(dod_handle* h, const float* pixels, int B, int H, int W, const
 }
 
 // DETRDecoder.forward (detr_decoder.py:47-83).  mem_op: memory in the operand dtype (bf16 in fast mode).
-int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& ws, float* det, hipStream_t s) {
+// l0_only: run layer 0's image-independent prefix for ONE image (ws sized for B = 1) and leave it in ws.tgt / ws.proj (dod_finalize_weights)
+int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& ws, float* det, hipStream_t s, bool l0_only = false) {
   const dod_config& g = h->cfg;
   const bool bf = is_bf16(h);
   const int Dd = g.dec_hidden, Q = g.num_queries, Hd = g.dec_heads, Pn = g.n_points, Fd = g.dim_feedforward, C = g.num_classes;
@@ -841,12 +857,13 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
   if (Dd % Hd) return fail(h, DOD_ERR_INVALID, "decoder hidden %d not divisible by heads %d", Dd, Hd);
   if (dh > 128 || dh % 4) return fail(h, DOD_ERR_INVALID, "decoder head_dim %d unsupported (<=128, multiple of 4)", dh);
   int rc;
-  tap(h, 1000, mem_op, bf, (size_t)M * Dd, s);
+  if (!l0_only) tap(h, 1000, mem_op, bf, (size_t)M * Dd, s);
   const bool x3 = is_x3(h) && ws.mem2;
-  if (x3) KCHK(h, launch_split2((const float*)mem_op, Dd, ws.mem2, M, Dd, s));   // memory-side projections as split products
-  KCHK(h, launch_bcast_rows(h->query, ws.tgt, 1, Q, Dd, s));                                                  // K10 (image 0; broadcast after layer 0's shared part)
+  if (x3 && !l0_only) KCHK(h, launch_split2((const float*)mem_op, Dd, ws.mem2, M, Dd, s));   // memory-side projections as split products
+  const bool l0_const = !l0_only && h->l0_tgt && (!g.use_deformable || h->l0_proj);          // layer 0's prefix comes from the pack-time constants
+  if (!l0_const) KCHK(h, launch_bcast_rows(h->query, ws.tgt, 1, Q, Dd, s));                                  // K10 (image 0; broadcast after layer 0's shared part)
   int fh = 0, fw = 0;
-  if (g.use_deformable) {
+  if (g.use_deformable && !l0_only) {
     spatial_factor(N, &fh, &fw);                                                                                // K16
     int u = 0;
     for (int j = 0; j < g.dec_layers; ++j) {                                                                    // K14 (once per distinct weight)
@@ -920,23 +937,27 @@ int decoder_impl(dod_handle* h, const void* mem_op, int B, int N, const DecWS& w
   int uniq_idx[64]; { int u = 0; for (int j = 0; j < g.dec_layers && j < 64; ++j) uniq_idx[j] = h->DL[j].vp_alias < 0 ? u++ : -1; }
   for (int j = 0; j < g.dec_layers; ++j) {
     const DLayer& L = h->DL[j];
-    const bool shared0 = (j == 0 && B > 1);          // layer 0: query rows identical for every image
-    rc = self_attn(L, shared0 ? 1 : B); if (rc) return rc;
+    const bool const0 = j == 0 && l0_const;          // layer 0's self-attention block (+ sampling projections): precomputed
+    const bool shared0 = (j == 0 && (B > 1 || const0));          // layer 0: query rows identical for every image
+    if (const0) { KCHK(h, launch_bcast_rows(h->l0_tgt, ws.tgt, B, Q, Dd, s)); tgt3 = nullptr; }
+    else { rc = self_attn(L, shared0 ? 1 : B); if (rc) return rc; }
     if (g.use_deformable) {
       // K12 + K13 fused small linear, then K15 gather
-      rc = linear(h, false, ws.tgt, Dd, L.cat_w, Dd, shared0 ? Q : BQ, h->ncat, Dd, epi(L.cat_b, ws.proj, nullptr, h->ncat), s); if (rc) return rc;
-      if (shared0) KCHK(h, launch_bcast_rows(ws.tgt, ws.tgt + (size_t)Q * Dd, B - 1, Q, Dd, s));   // rows of image 0 -> images 1..B-1
+      if (!const0) { rc = linear(h, false, ws.tgt, Dd, L.cat_w, Dd, shared0 ? Q : BQ, h->ncat, Dd, epi(L.cat_b, ws.proj, nullptr, h->ncat), s); if (rc) return rc; }
+      if (l0_only) return DOD_OK;                                                                   // ws.tgt rows 0..Q-1 and ws.proj hold the prefix
+      if (shared0 && !const0) KCHK(h, launch_bcast_rows(ws.tgt, ws.tgt + (size_t)Q * Dd, B - 1, Q, Dd, s));   // rows of image 0 -> images 1..B-1
       const int src = L.vp_alias >= 0 ? L.vp_alias : j;
       const float* vals = ws.values + (size_t)uniq_idx[src] * M * Dd;
       const bool s3 = fuse3 && splits(L.op_w3, BQ, Dd, Dd, ACT_NONE);
-      KCHK(h, launch_deform_sample(ws.proj, h->ncat, vals, B, Q, N, Hd, Pn, dh, fh, fw, ws.samp, s, shared0 ? 1 : 0, s3 ? ws.a3 : nullptr));
+      KCHK(h, launch_deform_sample(const0 ? h->l0_proj : ws.proj, h->ncat, vals, B, Q, N, Hd, Pn, dh, fh, fw, ws.samp, s, shared0 ? 1 : 0, s3 ? ws.a3 : nullptr));
       rc = qlinear(ws.samp, Dd, L.op_w, L.op_w3, BQ, Dd, epi(L.op_b, ws.t2, nullptr, Dd, ACT_NONE, nullptr, ws.tgt, Dd), s3 ? ws.a3 : nullptr); if (rc) return rc;   // K17
       const bool n3 = fuse3 && splits(L.l1w3, BQ, Fd, Fd, ACT_RELU);      // next reader of tgt: linear1
       KCHK(h, launch_layernorm(ws.t2, nullptr, L.n2w, L.n2b, g.dec_ln_eps, BQ, Dd, ws.tgt, nullptr, s, nullptr, nullptr, nullptr, 0, n3 ? ws.a3 : nullptr));
       tgt3 = n3 ? ws.a3 : nullptr;
     } else {
       // K20: dense cross-attention over all N memory tokens
-      if (shared0) KCHK(h, launch_bcast_rows(ws.tgt, ws.tgt + (size_t)Q * Dd, B - 1, Q, Dd, s));
+      if (l0_only) return DOD_OK;
+      if (shared0 && !const0) KCHK(h, launch_bcast_rows(ws.tgt, ws.tgt + (size_t)Q * Dd, B - 1, Q, Dd, s));
       rc = qlinear(ws.tgt, Dd, L.ca_q_w, L.ca_q_w3, BQ, Dd, epi(L.ca_q_b, ws.qd, nullptr, Dd), tgt3); if (rc) return rc;
       tgt3 = nullptr;
       if (x3 && L.ca_kv_w2) rc = linear3(h, ws.mem2, L.ca_kv_w2, M, 2 * Dd, Dd, epi(L.ca_kv_b, ws.kv, nullptr, 2 * Dd), s);
@@ -1069,7 +1090,37 @@ int dod_finalize_weights(dod_handle* h, void* stream) {
   if (!h) return fail(nullptr, DOD_ERR_INVALID, "null handle");
   { static const size_t mb = [] { const char* v = getenv("DINODET_GEMM_SCRATCH_MB"); return v && atoi(v) > 0 ? (size_t)atoi(v) : (size_t)64; }();
     (void)gemm_tail_reserve(mb << 20); }     // K-split scratch of the GEMMs' wave-quantisation tail (gemm_pp.hip): never allocated inside a forward
-  return finalize_impl(h, (hipStream_t)stream);
+  int rc = finalize_impl(h, (hipStream_t)stream);
+  if (rc || !h->has_dec) return rc;
+  // layer 0's image-independent prefix (dod_handle::l0_tgt / l0_proj) through the forward's own code path, one image, scratch freed afterwards
+  hipStream_t s = (hipStream_t)stream;
+  const dod_config& g = h->cfg;
+  const size_t Q = g.num_queries, Dd = g.dec_hidden;
+  h->l0_tgt = h->l0_proj = nullptr;
+  Carver sz(nullptr);
+  const size_t bytes = carve_decoder(h, sz, 1, 1, nullptr, false) + 256;
+  void* tmp = nullptr;
+  float *t0 = nullptr, *p0 = nullptr;
+  HIPCHK(h, hipMalloc(&tmp, bytes));
+  if (hipMalloc((void**)&t0, Q * Dd * 4) != hipSuccess || (g.use_deformable && hipMalloc((void**)&p0, Q * (size_t)h->ncat * 4) != hipSuccess)) {
+    (void)hipFree(tmp); if (t0) (void)hipFree(t0);
+    return fail(h, DOD_ERR_HIP, "allocation of the decoder's layer-0 constants failed");
+  }
+  h->owned.push_back(t0); if (p0) h->owned.push_back(p0);
+  Carver cv((void*)(((uintptr_t)tmp + 255) & ~(uintptr_t)255));
+  DecWS dw;
+  carve_decoder(h, cv, 1, 1, &dw, false);
+  rc = decoder_impl(h, nullptr, 1, 1, dw, nullptr, s, true);
+  if (!rc) {
+    hipError_t e1 = hipMemcpyAsync(t0, dw.tgt, Q * Dd * 4, hipMemcpyDeviceToDevice, s);
+    hipError_t e2 = p0 ? hipMemcpyAsync(p0, dw.proj, Q * (size_t)h->ncat * 4, hipMemcpyDeviceToDevice, s) : hipSuccess;
+    hipError_t e3 = hipStreamSynchronize(s);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(h, DOD_ERR_HIP, "decoder layer-0 constants: %s", hipGetErrorString(e3 != hipSuccess ? e3 : (e1 != hipSuccess ? e1 : e2)));
+  } else (void)hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  if (rc) return rc;
+  h->l0_tgt = t0; h->l0_proj = p0;
+  return DOD_OK;
 }
 
 int dod_prepare(dod_handle* h, int H, int W, void* stream) {
@@ -1364,6 +1415,10 @@ int dod_op_linear_ln(int family, const void* A, const void* W, const void* wexp,
   if (out_layout == 2) e.out_split = -N;
   if (out_layout == 3) e.out_h2 = 1;
   e.ln_stats = (const float2*)ln->stats; e.ln_c = ln->csum;
+  if (ln->part_in) {
+    if (!ln->stats || ln->stats_out == ln->stats) return fail(nullptr, DOD_ERR_INVALID, "part_in needs stats (the shift) and a DIFFERENT stats_out buffer");
+    e.ln_part_in = (const float2*)ln->part_in; e.ln_npart = (K + 127) / 128; e.ln_stats_out = (float2*)ln->stats_out; e.ln_eps = ln->eps;
+  }
   if (ln->part) {
     e.ln_part = (float2*)ln->part; e.ln_npart = (N + 127) / 128; e.ln_op = ln->op_out; e.ln_shift = (const float2*)ln->shift;
     e.ln_op_kind = family == DOD_PREC_FP16X2 ? LNOP_H2 : (family == DOD_PREC_BF16X3 ? LNOP_PAIR : LNOP_BF16);

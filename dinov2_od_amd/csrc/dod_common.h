@@ -178,8 +178,11 @@ struct GemmEpi {
   int ln_npart;           //   = ceil(N / 128)
   const float2* ln_shift; //   [M]: .x = the shift of row m (its previous mean; null = 0) -- ln_finalize_kernel reads the same value
   //   consumer (QKV, fc1 / weights_in): v = (acc - mean[m] c[n]) rstd[m] before the bias
-  const float2* ln_stats; //   [M] (mean, rstd), or null
+  const float2* ln_stats; //   [M] (mean, rstd), or null.  With ln_part_in: .x = the shift the producer subtracted, and the consumer finishes the statistics
   const float* ln_c;      //   [N]
+  const float2* ln_part_in; // [M][ln_npart] the producer's group sums, or null (ln_stats final: the first block, written by rowstats_kernel).  The tile
+  float2* ln_stats_out;   //   column n0 == 0 also writes the finished (mean, rstd) here -- ANOTHER buffer than ln_stats (other tiles still read the shift
+  float ln_eps;           //   there): the next producer's shift.  No kernel of its own merges the groups (24 launches of 3-5 us per forward).
 };
 enum { LNOP_BF16 = 1, LNOP_PAIR = 2, LNOP_H2 = 3 };
 

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
       stage_acc(smem, PITCH, wm * 64 + i * 32 + lr, wn * 64 + j * 32, acc[i][j], lh);
   const ColParams cp = load_col_params<BN, LN>(e, n0, N, tid);
   auto rowmap = [&](int row_l) { return m0 + row_l; };
-  stage_row_stats<BM, BN, LN>(smem, PITCH, e, M, tid, rowmap);
+  stage_row_stats<BM, BN, LN>(smem, PITCH, e, M, tid, rowmap, K, n0);
   __syncthreads();
   drain_tile<BM, BN, 256, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);
 }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
         *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
       }
     auto rowmap = [&](int row_l) { return m0 + (row_l >> 5) * 64 + pass * 32 + (row_l & 31); };
-    stage_row_stats<128, B5N, LN>(smem, PITCH, e, M, tid, rowmap);
+    stage_row_stats<128, B5N, LN>(smem, PITCH, e, M, tid, rowmap, K, n0);
     __syncthreads();
     drain_tile<128, B5N, 512, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);
   }

@@ -101,14 +101,27 @@ enum { LN_NONE = 0, LN_CONS = 1, LN_PROD = 2 };
 // padding behind each row of the staged tile: ONE vector-memory instruction per pass (threads 0..ROWS-1) instead of one per row visit.  The
 // epilogues are paced by their vector-memory INSTRUCTIONS, not their bytes: fetched per visit, the statistics cost the QKV GEMM +42 us and
 // fc1 +32 us (profiles/r04_lnfold_ab.txt).  Call between staging the accumulators and the barrier in front of the drain.
+// The consumer also FINISHES the statistics (GemmEpi::ln_part_in): mean = k + S / D, var = Q / D - (S / D)^2 from the producer's group sums of
+// (x - k), (x - k)^2 -- S / D is the change of the mean, a fraction of the row's spread, so nothing cancels -- D = this GEMM's K; every tile
+// recomputes its rows' pair (a dozen 8-byte loads per row and pass), the tiles of column 0 publish it for the next producer's shift.
 template <int ROWS, int COLS, int LN, typename RowMap>
-__device__ __forceinline__ void stage_row_stats(char* sm, int pitch, const GemmEpi& e, int M, int tid, RowMap rowmap) {
+__device__ __forceinline__ void stage_row_stats(char* sm, int pitch, const GemmEpi& e, int M, int tid, RowMap rowmap, int D = 0, int n0 = 0) {
   if (LN == LN_NONE) return;
   if (tid < ROWS) {
     const float2* src = LN == LN_CONS ? e.ln_stats : e.ln_shift;
     const int m = rowmap(tid);
     float2 st = make_float2(0.f, 0.f);
-    if (src && m < M) st = src[m];
+    if (src && m < M) {
+      st = src[m];
+      if (LN == LN_CONS && e.ln_part_in) {
+        const float2* p = e.ln_part_in + (size_t)m * e.ln_npart;
+        float S = 0.f, Q = 0.f;
+        for (int g = 0; g < e.ln_npart; ++g) { const float2 pg = p[g]; S += pg.x; Q += pg.y; }
+        const float dm = S / (float)D;
+        st = make_float2(st.x + dm, 1.0f / sqrtf(fmaxf(Q / (float)D - dm * dm, 0.f) + e.ln_eps));
+        if (n0 == 0 && e.ln_stats_out) e.ln_stats_out[m] = st;
+      }
+    }
     *reinterpret_cast<float2*>(sm + tid * pitch + COLS * 4) = st;
   }
 }

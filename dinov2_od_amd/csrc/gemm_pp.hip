@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void gemm_ppm_256x256_kernel(const bf16_t* __r
         *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
       }
     auto rowmap = [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); };
-    stage_row_stats<128, PPN, LN>(smem, PITCH, e, M, tid, rowmap);
+    stage_row_stats<128, PPN, LN>(smem, PITCH, e, M, tid, rowmap, K, n0);
     __syncthreads();
     if (wide) drain_tile_bf16x8<128, PPN, 512, LN>(smem, PITCH, e, M, N, n0, tid, rowmap);
     else drain_tile<128, PPN, 512, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(512) void gemm_h2_256x256_kernel(const char* __rest
 #pragma unroll
       for (int j = 0; j < 2; ++j) stage_acc(smem, PITCH, grp_ * 64 + ii * 32 + lr, wq * 64 + j * 32, acc[pass * 2 + ii][j], lg);
     auto rowmap = [&](int row_l) { return m0 + (row_l >> 6) * 128 + pass * 64 + (row_l & 63); };
-    stage_row_stats<128, PPN, LN>(smem, PITCH, e, M, tid, rowmap);
+    stage_row_stats<128, PPN, LN>(smem, PITCH, e, M, tid, rowmap, K, n0);
     __syncthreads();
     if (wide) drain_tile_bf16x8<128, PPN, 512, LN>(smem, PITCH, e, M, N, n0, tid, rowmap);
     else drain_tile<128, PPN, 512, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);
@@ -574,7 +574,7 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
 #define KSR_ROWS 16      // rows per workgroup of the reduce launch: 16 x 256 outputs, so that a 384-row remainder still spreads over 72 CUs
 template <int LN>
 __global__ __launch_bounds__(512) void gemm_ksplit_reduce_kernel(const float* __restrict__ part, long long slice_stride, int S, int R, int N,
-                                                                 GemmEpi e, int m_base, int M) {
+                                                                 GemmEpi e, int m_base, int M, int K) {
   __shared__ __attribute__((aligned(16))) char smem[KSR_ROWS * (PPN * 4 + 16)];
   constexpr int PITCH = PPN * 4 + 16;
   const int tid = threadIdx.x;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(512) void gemm_ksplit_reduce_kernel(const float* __
     *reinterpret_cast<float4*>(smem + rl * PITCH + c4 * 16) = acc;
   }
   auto rowmap = [&](int row_l) { return m_base + r0 + row_l; };
-  stage_row_stats<KSR_ROWS, PPN, LN>(smem, PITCH, e, M, tid, rowmap);
+  stage_row_stats<KSR_ROWS, PPN, LN>(smem, PITCH, e, M, tid, rowmap, K, n0);
   __syncthreads();
   const ColParams cp = load_col_params<PPN, LN>(e, n0, N, tid);
   if (drain8_ok(e, N)) drain_tile_bf16x8<KSR_ROWS, PPN, 512, LN>(smem, PITCH, e, M, N, n0, tid, rowmap);
@@ -735,7 +735,7 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
   if (hipGetLastError() != hipSuccess) return 3;
   // ---- reduce + the caller's epilogue on global rows Mmain..M-1
   ++g_tail_splits;
-#define GO_(LN_) hipLaunchKernelGGL(gemm_ksplit_reduce_kernel<LN_>, dim3((R + KSR_ROWS - 1) / KSR_ROWS, tiles_n), dim3(512), 0, s, scratch, (long long)slab, S, R, N, e, Mmain, M);
+#define GO_(LN_) hipLaunchKernelGGL(gemm_ksplit_reduce_kernel<LN_>, dim3((R + KSR_ROWS - 1) / KSR_ROWS, tiles_n), dim3(512), 0, s, scratch, (long long)slab, S, R, N, e, Mmain, M, K);
   LN_DISPATCH(e, GO_)
 #undef GO_
   return hipGetLastError() == hipSuccess ? 0 : 3;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(1024) void gemm_x3_256x256_kernel(const bf16_t* __r
         *reinterpret_cast<float4*>(smem + row_l * PITCH + col * 4) = make_float4(a[0], a[1], a[2], a[3]);                   \
       }                                                                                                                     \
     auto rowmap = [&](int row_l) { return m0 + (row_l >> 5) * 64 + (P) * 32 + (row_l & 31); };                              \
-    stage_row_stats<128, X3N, LN>(smem, PITCH, e, M, tid, rowmap);                                                          \
+    stage_row_stats<128, X3N, LN>(smem, PITCH, e, M, tid, rowmap, K, n0);                                                          \
     __syncthreads();                                                                                                        \
     if (wide) drain_tile_bf16x8<128, X3N, 1024, LN>(smem, PITCH, e, M, N, n0, tid, rowmap);                                 \
     else drain_tile<128, X3N, 1024, LN>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);                                         \

@@ -214,7 +214,10 @@ int dod_op_linear_h2(const void* A, const void* W, const void* wexp, int M, int 
                      const float* resid, int ldr, void* out, int out_layout, int ldc, int act, void* stream);
 /* LayerNorm folded into the GEMMs around it (the fast modes' schedule of modeling_dinov2.py:361-380, x -> LN -> linear): with
  * W' = W diag(gamma), c[n] = sum_k W'[n][k] and b' = b + W beta,   LN(x) W^T + b = rstd (x W'^T - mean c) + b'.
- *   consumer (stats, csum set): A holds the residual rows x themselves in the family's operand format, W holds W', bias holds b';
+ *   consumer (stats, csum set): A holds the residual rows x themselves in the family's operand format, W holds W', bias holds b'; with part_in
+ *     (a producer's group sums [M][ceil(K / 128)][2]; stats[m][0] = the shift it used) the consumer finishes the statistics itself in its
+ *     epilogue (eps: the LayerNorm's) and the tiles of output column 0 write them to stats_out [M][2] (a different buffer than stats) -- what the
+ *     forward does since round 4: no launch of its own merges the groups;
  *   producer (part set; out_layout 0 with a residual): beside the fp32 rows it writes them in the family's operand format to op_out
  *     ([M, N] bf16 / pair layout [M, 2N] / H2 rows) and (sum, sum of squares) of (row - shift[m][0]) per 128-column group to
  *     part [M][ceil(N / 128)][2]; shift [M][2] (or NULL = 0): a value near the row's mean -- the forward passes the row's previous
@@ -228,6 +231,9 @@ typedef struct dod_ln_fold {
   void* op_out;
   void* part;
   const void* shift;
+  const void* part_in;
+  void* stats_out;
+  float eps;
 } dod_ln_fold;
 int dod_op_linear_ln(int family, const void* A, const void* W, const void* wexp, int M, int N, int K, const float* bias, const float* scale,
                      const float* resid, int ldr, void* out, int out_layout, int ldc, int act, const dod_ln_fold* ln, void* stream);

@@ -91,7 +91,7 @@ def test_residual_epilogue_emits_operand_rows_and_statistics(fam, M, D, K, shift
     stats = torch.zeros(M, 2, device="cuda")
     if shifted:
         stats[:, 0] = x0.mean(-1)
-    ln = nat.DodLnFold(None, None, op.data_ptr(), part.data_ptr(), stats.data_ptr() if shifted else None)
+    ln = nat.DodLnFold(None, None, op.data_ptr(), part.data_ptr(), stats.data_ptr() if shifted else None, None, None, 0.0)
     nat.check(L.dod_op_linear_ln(FAM[fam], nat.ptr(Aop), nat.ptr(Wop), nat.ptr(wexp), M, D, K, nat.ptr(bias), nat.ptr(ls), nat.ptr(x), D,
                                  nat.ptr(x), 0, D, 0, C.byref(ln), nat.stream_ptr()))
     nat.check(L.dod_op_ln_finalize(nat.ptr(part), M, D, EPS, nat.ptr(stats), nat.stream_ptr()))
@@ -141,7 +141,7 @@ def test_folded_consumer_equals_layernorm_then_linear(fam, M, N, D, act):
     Wop, wexp = _operand(Wp, fam, weight=True)
     out_layout = 1 if fam == "bf16" else (3 if (fam == "fp16x2" and act == "gelu" and N % 32 == 0) else 2)
     out = torch.zeros(M, N if fam == "bf16" else 2 * N, dtype=torch.bfloat16, device="cuda")
-    ln = nat.DodLnFold(stats.data_ptr(), csum.data_ptr(), None, None, None)
+    ln = nat.DodLnFold(stats.data_ptr(), csum.data_ptr(), None, None, None, None, None, 0.0)
     nat.check(L.dod_op_linear_ln(FAM[fam], nat.ptr(xop), nat.ptr(Wop), nat.ptr(wexp), M, N, D, nat.ptr(bp), None, None, 0, nat.ptr(out), out_layout,
                                  N if fam == "bf16" else 2 * N, nat.ACT[act], C.byref(ln), nat.stream_ptr()))
     torch.cuda.synchronize()
@@ -175,3 +175,51 @@ def test_folded_consumer_equals_layernorm_then_linear(fam, M, N, D, act):
         if act == "gelu":
             full = torch.nn.functional.gelu(full)
         assert rel_err(got.numpy(), full.numpy()) < 3e-2
+
+
+@pytest.mark.parametrize("fam", list(FAM))
+@pytest.mark.parametrize("M,D,N", [(517, 384, 1152), (2740, 768, 2304), (64 * 1370, 768, 2304), (8224, 768, 3072)], ids=lambda v: str(v))
+def test_consumer_finishes_the_statistics_itself(fam, M, D, N):
+    """What the forward runs since round 4: a residual GEMM (producer) leaves group sums relative to the rows' previous mean; the NEXT GEMM
+    (consumer) turns them into (mean, rstd) in its own epilogue -- no launch merges the groups -- and its column-0 tiles publish them.
+    Bit-equal to the two-step form (dod_op_ln_finalize, then a consumer on final statistics), and the published statistics equal that
+    kernel's."""
+    L = nat.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + D + N)
+    K = D
+    A = torch.randn(M, K, device="cuda", generator=g)
+    Wo = torch.randn(D, K, device="cuda", generator=g) * 0.05
+    x0 = _rows(M, D, 23)
+    Aop, _ = _operand(A, fam)
+    Woop, woexp = _operand(Wo, fam, weight=True)
+    npart = (D + 127) // 128
+    part = torch.empty(M, npart, 2, device="cuda")
+    xop = torch.zeros(M, D if fam == "bf16" else 2 * D, dtype=torch.bfloat16, device="cuda")
+    shift = torch.zeros(M, 2, device="cuda")
+    shift[:, 0] = x0.mean(-1)
+    x = x0.clone()
+    ln = nat.DodLnFold(None, None, xop.data_ptr(), part.data_ptr(), shift.data_ptr(), None, None, 0.0)
+    nat.check(L.dod_op_linear_ln(FAM[fam], nat.ptr(Aop), nat.ptr(Woop), nat.ptr(woexp), M, D, K, None, None, nat.ptr(x), D, nat.ptr(x), 0, D, 0,
+                                 C.byref(ln), nat.stream_ptr()))
+    W = torch.randn(N, D, device="cuda", generator=g) * 0.05
+    b = torch.randn(N, device="cuda", generator=g) * 0.1
+    csum = (W.bfloat16().float() if fam == "bf16" else W).double().sum(-1).float()
+    Wop, wexp = _operand(W, fam, weight=True)
+    ldo = N if fam == "bf16" else 2 * N
+    lay = 1 if fam == "bf16" else 2
+    # (a) two steps
+    st_a = shift.clone()
+    nat.check(L.dod_op_ln_finalize(nat.ptr(part), M, D, EPS, nat.ptr(st_a), nat.stream_ptr()))
+    out_a = torch.zeros(M, ldo, dtype=torch.bfloat16, device="cuda")
+    ln_a = nat.DodLnFold(st_a.data_ptr(), csum.data_ptr(), None, None, None, None, None, 0.0)
+    nat.check(L.dod_op_linear_ln(FAM[fam], nat.ptr(xop), nat.ptr(Wop), nat.ptr(wexp), M, N, D, nat.ptr(b), None, None, 0, nat.ptr(out_a), lay, ldo, 0,
+                                 C.byref(ln_a), nat.stream_ptr()))
+    # (b) the consumer finishes the statistics
+    st_b = torch.full((M, 2), float("nan"), device="cuda")
+    out_b = torch.zeros(M, ldo, dtype=torch.bfloat16, device="cuda")
+    ln_b = nat.DodLnFold(shift.data_ptr(), csum.data_ptr(), None, None, None, part.data_ptr(), st_b.data_ptr(), EPS)
+    nat.check(L.dod_op_linear_ln(FAM[fam], nat.ptr(xop), nat.ptr(Wop), nat.ptr(wexp), M, N, D, nat.ptr(b), None, None, 0, nat.ptr(out_b), lay, ldo, 0,
+                                 C.byref(ln_b), nat.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(st_a, st_b), "published statistics differ from the finalize kernel's"
+    assert torch.equal(out_a, out_b)
