@@ -1026,6 +1026,7 @@ int dod_test_set_option(const char* name, int value) {
 }
 long dod_test_counter(const char* name) {
   if (name && !strcmp(name, "tail_splits")) return gemm_tail_split_count();
+  if (name && !strcmp(name, "rem_cuts")) return gemm_rem_cut_count();
   return -1;
 }
 

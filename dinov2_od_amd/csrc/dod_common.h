@@ -28,6 +28,7 @@ enum { DOD_OPT_TAILSPLIT = 0,         // GEMM wave-quantisation tail split: 0 of
        DOD_OPT_COUNT };
 int dod_option(int which);            // dod_api.hip; -1 when unset
 long gemm_tail_split_count();         // gemm_pp.hip: GEMM calls that took the tail-split path so far
+long gemm_rem_cut_count();            // gemm_bf16.hip: GEMM calls whose short last round ran as a launch of its own
 
 #ifdef DINODET_TUNING
 #define DOD_TUNE_ENV(name) getenv(name)
@@ -185,6 +186,25 @@ struct GemmEpi {
   float ln_eps;           //   there): the next producer's shift.  No kernel of its own merges the groups (24 launches of 3-5 us per forward).
 };
 enum { LNOP_BF16 = 1, LNOP_PAIR = 2, LNOP_H2 = 3 };
+// The epilogue of rows m0.. of the same GEMM as a launch of its own (row 0 of the result = row m0 of `e`): every per-row pointer moves down m0
+// rows.  Only for epilogues whose rows are independent of their index (no rows_per_img / pos map, no K slices, no fp8 scales): gemm_epi_rows_ok.
+inline bool gemm_epi_rows_ok(const GemmEpi& e) {
+  return e.rows_per_img == 0 && !e.pos && e.ksplit <= 1 && !e.a_scale && !e.a_bs && !e.out_bs;
+}
+inline GemmEpi gemm_epi_rows(const GemmEpi& e, int m0) {
+  GemmEpi r = e;
+  const size_t m = (size_t)m0;
+  if (r.resid) r.resid += m * r.ldr;
+  if (r.out_f32) r.out_f32 += m * r.ldc;
+  if (r.out_bf16) r.out_bf16 += m * r.ldc;
+  if (r.ln_op) r.ln_op = reinterpret_cast<char*>(r.ln_op) + m * (size_t)r.ln_op_ld * 2;      // every kind: ln_op_ld 2-byte units per row (gemm_epi.h ln_store_op)
+  if (r.ln_part) r.ln_part += m * r.ln_npart;
+  if (r.ln_shift) r.ln_shift += m;
+  if (r.ln_stats) r.ln_stats += m;
+  if (r.ln_part_in) r.ln_part_in += m * r.ln_npart;
+  if (r.ln_stats_out) r.ln_stats_out += m;
+  return r;
+}
 
 // ----------------------------------------------------------------------------- launchers (all enqueue on `s`, no sync)
 // gemm: C = A[M,K] (row-major, lda) x W[N,K]^T (row-major, ldw)

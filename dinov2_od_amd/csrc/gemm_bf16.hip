@@ -18,6 +18,7 @@
 // contiguous run, so the ~64 tiles resident on an XCD share 8 A panels and 8 W panels (3 MiB < 4 MiB L2).
 #include "dod_common.h"
 #include "gemm_epi.h"
+#include <atomic>
 #include <cstdlib>
 
 #define BM 128
@@ -27,7 +28,11 @@
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <int LN>
+// SLOTS: K-tiles of the LDS ring.  2 (64 KiB, two workgroups per CU): tile t+1 streams in while tile t feeds the MFMAs.  3 (96 KiB, one
+// workgroup per CU; round 4): TWO tiles in flight behind a counted vmcnt -- for grids of at most one workgroup per CU (the decoder's
+// query-side linears, the cut-off last round of a block GEMM), where nothing else on the CU hides the DMA latency and a K step of the
+// 2-slot form lasts one memory round trip (~1.1 us for 0.15 us of MFMAs).
+template <int LN, int SLOTS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int lda,
                                                         const bf16_t* __restrict__ W, int ldw,
                                                         int M, int N, int K, GemmEpi e) {
@@ -97,11 +102,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 
   const int nk = K / BK;
   STAGE(0, 0)
-  __syncthreads();      // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+  if (SLOTS > 2 && nk > 1) STAGE(1, BK)
   const int lr = lane & 31, lh = lane >> 5;
+  int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) STAGE((kt + 1) & 1, (kt + 1) * BK)
-    const char* sA = smem + (kt & 1) * STAGE_BYTES;
+    // tile kt has landed (8 DMA instructions per wave and tile; SLOTS - 2 younger tiles may stay in flight); the barrier also says every
+    // wave has finished reading tile kt - 1, whose slot the next DMA refills
+    if (SLOTS > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + SLOTS - 1 < nk) {
+      const int ns = slot + SLOTS - 1 >= SLOTS ? slot - 1 : slot + SLOTS - 1;
+      STAGE(ns, (kt + SLOTS - 1) * BK)
+    }
+    const char* sA = smem + slot * STAGE_BYTES;
     const char* sW = sA + BM * BK * 2;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -119,8 +134,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+    slot = slot + 1 == SLOTS ? 0 : slot + 1;
   }
+  __syncthreads();
 
   // all ring reads are done (last barrier of the loop); reuse the ring as the fp32 output tile
   constexpr int PITCH = BN * 4 + 16;
@@ -275,7 +291,11 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_256x128_m16_kernel(const bf1
 
 // dynamic LDS: the staging ring, or the padded fp32 epilogue tile if larger
 static constexpr int LDS128 = (BM * (BN * 4 + 16)) > 2 * STAGE_BYTES ? (BM * (BN * 4 + 16)) : 2 * STAGE_BYTES;
+static constexpr int LDS128R = 3 * STAGE_BYTES;
 static constexpr int LDS5 = (128 * (B5N * 4 + 16)) > B5_SLOTS * B5_STAGE ? (128 * (B5N * 4 + 16)) : B5_SLOTS * B5_STAGE;
+
+static std::atomic<long> g_rem_cuts{0};
+long gemm_rem_cut_count() { return g_rem_cuts.load(); }
 
 int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K,
                      const GemmEpi& e, hipStream_t s) {
@@ -283,11 +303,13 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   if (K % BK != 0 || N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
+  if (!gemm_epi_ln_ok(e, N)) return 2;
   static bool attr_set[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-#define ATTR_(LN_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<LN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS128); \
+#define ATTR_(LN_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<LN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS128); \
+                   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<LN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS128R); \
                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256x128_m16_kernel<LN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
     ATTR_(LN_NONE) ATTR_(LN_CONS) ATTR_(LN_PROD)
 #undef ATTR_
@@ -323,7 +345,26 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
     // (tools/bench_pp.py, rows 8 224 / 10 960 / 43 840 / 87 680: QKV 46.9 / 53.2 / 173.0 / 338.2 us against 51.8 / 56.8 / 186.6 / 345.5 for the
     // round-3 choice, fc1 59.9 / 87.7 / 264.2 / 518.9 against 63.8 / 104.7 / 297.9 / 548.4); the narrow ones (N = 768) keep the round rule
     // below, and the long-K narrow one (fc2) the ping-pong kernel behind its tail split.
-    if (N >= 1536 && K < 2048) return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
+    if (N >= 1536 && K < 2048) {
+      // A last round of a few tiles costs these short-K GEMMs a whole tile time when the grid is only one or two rounds deep (8 images of
+      // 518^2: fc1 = 43 x 12 = 516 tiles = two rounds + 4; 32 images of 224^2: QKV = 33 x 9 = 297 = one round + 41).  The m-tiles of that
+      // round are cut off and run as a launch of their own, which the small-M rules below spread over the chip as 128-row tiles.
+      const long rounds = t_big / cu, rem = t_big % cu;
+      static const int rem_div = [] { const char* v = DOD_TUNE_ENV("DINODET_GEMM_REMCUT"); return v ? atoi(v) : 6; }();      // 0: off
+      // (rem >= CUs / 16: a handful of lone tiles finish at well under a tile time -- and a second stream's kernels fill the idle CUs -- so cutting
+      // them costs more than it saves: 2 x 4 images of 518^2, fc1 = 264 tiles, 1 737 against 1 794 images/s with the cut)
+      if (rounds >= 1 && rounds <= 2 && rem * 16 >= cu && rem_div > 0 && rem * rem_div <= cu && gemm_epi_rows_ok(e)) {
+        const int tn = (N + 255) / 256;
+        const int Mmain = (int)((rounds * cu) / tn) * 256, R = M - Mmain;
+        if (Mmain >= 2048 && R > 0 && R < 2048) {
+          const int rc = launch_gemm_bf16_k64(A, lda, W, ldw, Mmain, N, K, e, s);
+          if (rc) return rc;
+          ++g_rem_cuts;
+          return launch_gemm_bf16(A + (size_t)Mmain * lda, lda, W, ldw, R, N, K, gemm_epi_rows(e, Mmain), s);
+        }
+      }
+      return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
+    }
     if (c_big <= c_small * 1.02) {
       if (K >= 2048) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
       return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
@@ -342,9 +383,16 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
     LN_DISPATCH(e, GO_M16)
   } else {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-#define GO_128(LN_) hipLaunchKernelGGL(gemm_bf16_kernel<LN_>, dim3(tiles), dim3(256), LDS128, s, A, lda, W, ldw, M, N, K, e);
-    LN_DISPATCH(e, GO_128)
+    // a grid of at most one workgroup per CU has nothing beside it to hide its DMA latency: the 3-slot ring (two K-tiles in flight)
+    static const int ring = [] { const char* v = DOD_TUNE_ENV("DINODET_GEMM_RING"); return v ? atoi(v) : 1; }();
+    int cu128 = 256;
+    { static int cus[16] = {}; if (dev >= 0 && dev < 16) { if (!cus[dev]) { int c = 0; (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); cus[dev] = c > 0 ? c : 256; } cu128 = cus[dev]; } }
+#define GO_128(LN_) hipLaunchKernelGGL((gemm_bf16_kernel<LN_, 2>), dim3(tiles), dim3(256), LDS128, s, A, lda, W, ldw, M, N, K, e);
+#define GO_128R(LN_) hipLaunchKernelGGL((gemm_bf16_kernel<LN_, 3>), dim3(tiles), dim3(256), LDS128R, s, A, lda, W, ldw, M, N, K, e);
+    if (ring && tiles <= cu128 && K >= 3 * BK) { LN_DISPATCH(e, GO_128R) }
+    else { LN_DISPATCH(e, GO_128) }
 #undef GO_128
+#undef GO_128R
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -509,6 +509,7 @@ int launch_gemm_bf16_ppm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int
   if (N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
+  if (!gemm_epi_ln_ok(e, N)) return 2;
   ppm_attr();
   int gm = gemm_tile_mode();
   const int tiles = wres_grid(M, N, &gm);
@@ -525,6 +526,7 @@ int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int 
   if (e.out_f32 && e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
+  if (!gemm_epi_ln_ok(e, N)) return 2;
   ppm_attr();
   int gm = gemm_tile_mode();
   const int tiles = wres_grid(M, N, &gm);
@@ -553,6 +555,7 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
   if (e.out_f32 && e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
+  if (!gemm_epi_ln_ok(e, N)) return 2;
   { const int No = e.glu ? N / 2 : N;     // columns of the output row (GemmEpi::glu: the gate halves them)
     if (e.out_h2 && (No % 32 != 0 || e.ldc < 2 * No || e.ldc % 8 != 0 || e.out_split != 0)) return 2;
     if (e.glu && e.out_h2 && (N % 8 != 0)) return 2; }
@@ -689,8 +692,13 @@ int gemm_tail_split(int kind, const void* A, int lda, const void* W, int ldw, in
     // (with the engine's two concurrent micro-batches the other stream's kernels fill the last-round bubble anyway: fp16x2 at 2 x 32
     // images 1 198 images/s with the split, 1 208 without; so case (b) is kept for the launches that only a single-stream forward of a
     // large batch makes, M >= 65536 rows)
-    if (M < 8192 || (!force && (K < 2048 || M < 65536))) return -1;
     const int rounds = tiles / CU, rem = tiles % CU;
+    // (round 4) a grid one or two rounds deep whose last round is 6-16 % full -- the compensated QKV at 32 images of 224^2: 33 x 9 = 297 tiles --
+    // loses most of a tile time to it at any K (bench.py --workload vitb224: bf16x3 4 953 -> 5 015 images/s, fp16x2 5 258 -> 5 318; a fuller or
+    // emptier last round, e.g. 2 x 4 images of 518^2, gains nothing).  The plain bf16 kernels cut those rows off instead (gemm_bf16.hip).
+    const bool shallow = kind >= 1 && M >= 4096 && rounds >= 1 && rounds <= 2 && rem * 16 >= CU && rem * 6 <= CU;
+    if (M < 8192 && !shallow) return -1;
+    if (!force && !shallow && (K < 2048 || M < 65536)) return -1;
     if (rounds < 1 || rounds > 6 || rem == 0) return -1;
     const int m_main = (rounds * CU) / tiles_n;
     Mmain = m_main * PPM; R = M - Mmain;

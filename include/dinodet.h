@@ -399,7 +399,8 @@ int dod_reserve_gemm_scratch(size_t bytes);
  *   "no_fused_patch"   1 = the explicit im2col + GEMM patch embedding (read by dod_finalize_weights)
  *   "ln_fold"          0 = LayerNorm kernels instead of the folded form (read by dod_finalize_weights)
  *   "deterministic"    1 = ordered reductions instead of fp32 atomics in the training step's weight gradients (also DINODET_DETERMINISTIC=1)
- * dod_test_counter("tail_splits"): GEMM calls that took the tail-split path so far; -1 for an unknown name.
+ * dod_test_counter("tail_splits"): GEMM calls that took the tail-split path so far; "rem_cuts": GEMM calls whose short last round ran as a
+ * launch of its own (gemm_bf16.hip); -1 for an unknown name.
  * The in-kernel time stamps, the register-only MFMA probes and every tile / schedule override of the tuning rounds exist only in
  * -DDINODET_TUNING builds (include/dinodet_tuning.h); the release library exports none of them. */
 int dod_test_set_option(const char* name, int value);

@@ -117,7 +117,9 @@ def test_residual_epilogue_emits_operand_rows_and_statistics(fam, M, D, K, shift
 
 
 CONS = [(300, 1152, 384, "none"), (517, 520, 192, "gelu"), (2740, 2304, 768, "none"), (64 * 1370, 2304, 768, "none"), (64 * 1370, 3072, 768, "gelu"),
-        (8224, 3072, 768, "gelu")]
+        (8224, 3072, 768, "gelu"),
+        # grids of one / two rounds of 256x256 tiles plus a few: the last round's rows run as a launch of their own (gemm_bf16.hip, round 4)
+        (8224, 2304, 768, "none"), (8 * 1370, 3072, 768, "gelu")]
 
 
 @pytest.mark.parametrize("fam", list(FAM))
@@ -142,9 +144,12 @@ def test_folded_consumer_equals_layernorm_then_linear(fam, M, N, D, act):
     out_layout = 1 if fam == "bf16" else (3 if (fam == "fp16x2" and act == "gelu" and N % 32 == 0) else 2)
     out = torch.zeros(M, N if fam == "bf16" else 2 * N, dtype=torch.bfloat16, device="cuda")
     ln = nat.DodLnFold(stats.data_ptr(), csum.data_ptr(), None, None, None, None, None, 0.0)
+    cuts0 = L.dod_test_counter(b"rem_cuts")
     nat.check(L.dod_op_linear_ln(FAM[fam], nat.ptr(xop), nat.ptr(Wop), nat.ptr(wexp), M, N, D, nat.ptr(bp), None, None, 0, nat.ptr(out), out_layout,
                                  N if fam == "bf16" else 2 * N, nat.ACT[act], C.byref(ln), nat.stream_ptr()))
     torch.cuda.synchronize()
+    if fam == "bf16" and (M, N) in ((8224, 2304), (8 * 1370, 3072)) and torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert L.dod_test_counter(b"rem_cuts") == cuts0 + 1, "this shape is meant to exercise the cut-off last round"
     rows = _sample(M)
     xd = x[rows].double().cpu()
     mean = xd.mean(-1, keepdim=True)
@@ -178,7 +183,8 @@ def test_folded_consumer_equals_layernorm_then_linear(fam, M, N, D, act):
 
 
 @pytest.mark.parametrize("fam", list(FAM))
-@pytest.mark.parametrize("M,D,N", [(517, 384, 1152), (2740, 768, 2304), (64 * 1370, 768, 2304), (8224, 768, 3072)], ids=lambda v: str(v))
+@pytest.mark.parametrize("M,D,N", [(517, 384, 1152), (2740, 768, 2304), (64 * 1370, 768, 2304), (8224, 768, 3072), (8224, 768, 2304), (8 * 1370, 768, 3072)],
+                         ids=lambda v: str(v))
 def test_consumer_finishes_the_statistics_itself(fam, M, D, N):
     """What the forward runs since round 4: a residual GEMM (producer) leaves group sums relative to the rows' previous mean; the NEXT GEMM
     (consumer) turns them into (mean, rstd) in its own epilogue -- no launch merges the groups -- and its column-0 tiles publish them.
