@@ -303,7 +303,6 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
   if (K % BK != 0 || N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
-  if (!gemm_epi_ln_ok(e, N)) return 2;
   static bool attr_set[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);

@@ -164,81 +164,29 @@ __device__ __forceinline__ float half32_sum_hi(float v) {
   v += dpp_pick<0x142, 0xa>(v);
   return v;
 }
-// The new residual rows in the operand format of the GEMM that reads them next (GemmEpi::ln_op; the writers of rowops.hip's LayerNorm).
-// A thread holds four columns of a row per visit, i.e. 8 bytes of bf16 -- and the drain is paced by its vector-memory INSTRUCTIONS, not their
-// bytes.  Lanes 2i / 2i+1 hold columns n8..n8+3 / n8+4..n8+7 of the same rows, so over a PAIR of visits they trade halves
-// (one DPP quad_perm per dword): the even lane stores eight columns of the first row, the odd lane eight columns of the second --
-// 16-byte stores, half as many.  Needs N % 8 == 0 and 16-byte aligned operand rows (the launchers check: gemm_epi_ln_ok).
-struct OpQuad { unsigned d0, d1, d2, d3; };      // LNOP_BF16: d0 d1 = bf16 x 4;  LNOP_PAIR: + d2 d3 = the remainders;  LNOP_H2: d0 d1 = fp16 x 4, d2 = e4m3(h) x 4, d3 = e4m3(l 2^11) x 4
-__device__ __forceinline__ OpQuad ln_pack_op(int kind, const float4& v) {
-  OpQuad q;
-  if (kind == LNOP_H2) {
-    uint2 f16;
-    h2_quad(v, 1.0f, f16, q.d2, q.d3);
-    q.d0 = f16.x; q.d1 = f16.y;
-    return q;
-  }
-  q.d0 = pack2bf(v.x, v.y);
-  q.d1 = pack2bf(v.z, v.w);
-  q.d2 = q.d3 = 0u;
-  if (kind == LNOP_PAIR) {
-    q.d2 = pack2bf(v.x - __uint_as_float(q.d0 << 16), v.y - __uint_as_float(q.d0 & 0xffff0000u));
-    q.d3 = pack2bf(v.z - __uint_as_float(q.d1 << 16), v.w - __uint_as_float(q.d1 & 0xffff0000u));
-  }
-  return q;
-}
-__device__ __forceinline__ unsigned dpp_swap1(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true); }
-// a / b: this lane's quads of rows ma / mb (columns n..n+3).  EVERY lane of the wave must call this (DPP).
-__device__ __forceinline__ void ln_store_op_pair(const GemmEpi& e, int ma, int mb, bool oka, bool okb, int n, int N, const OpQuad& a, const OpQuad& b) {
-  const bool odd = (n >> 2) & 1;
-  const int kind = e.ln_op_kind;
-  // the even lane keeps row ma and needs the odd lane's quad of it; the odd lane keeps row mb
-  const unsigned k0 = odd ? b.d0 : a.d0, k1 = odd ? b.d1 : a.d1, s0 = odd ? a.d0 : b.d0, s1 = odd ? a.d1 : b.d1;
-  const unsigned r0 = dpp_swap1(s0), r1 = dpp_swap1(s1);
-  const size_t m = (size_t)(odd ? mb : ma);
-  const bool ok = odd ? okb : oka;
-  const int n8 = n & ~7;
-  const uint4 w01 = odd ? make_uint4(r0, r1, k0, k1) : make_uint4(k0, k1, r0, r1);
-  if (kind == LNOP_BF16) {
-    if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.ln_op) + m * (size_t)e.ln_op_ld + n8) = w01;
-    return;
-  }
-  const unsigned k2 = odd ? b.d2 : a.d2, k3 = odd ? b.d3 : a.d3, s2 = odd ? a.d2 : b.d2, s3 = odd ? a.d3 : b.d3;
-  const unsigned r2 = dpp_swap1(s2), r3 = dpp_swap1(s3);
-  if (kind == LNOP_PAIR) {
-    const uint4 w23 = odd ? make_uint4(r2, r3, k2, k3) : make_uint4(k2, k3, r2, r3);
-    bf16_t* o = reinterpret_cast<bf16_t*>(e.ln_op) + m * (size_t)e.ln_op_ld + n8;
-    if (ok) { *reinterpret_cast<uint4*>(o) = w01; *reinterpret_cast<uint4*>(o + (e.ln_op_ld >> 1)) = w23; }
-    return;
-  }
-  // H2 row: fp16 x K | per 16-k group: 16 x e4m3(h), 16 x e4m3(l 2^11) -- eight columns = 8 + 8 bytes, 16 apart
-  char* row = reinterpret_cast<char*>(e.ln_op) + m * (size_t)e.ln_op_ld * 2;
-  if (ok) {
-    *reinterpret_cast<uint4*>(row + 2 * n8) = w01;
-    char* p8 = row + h2_off8(N, n8);
-    *reinterpret_cast<uint2*>(p8) = odd ? make_uint2(r2, k2) : make_uint2(k2, r2);
-    *reinterpret_cast<uint2*>(p8 + 16) = odd ? make_uint2(r3, k3) : make_uint2(k3, r3);
-  }
-}
-#ifdef DINODET_AB_NO_OP_PAIR
-__device__ __forceinline__ void ln_store_op_row(const GemmEpi& e, size_t m, int n, int N, const OpQuad& q) {
+// the new residual row in the operand format of the GEMM that reads it next (GemmEpi::ln_op; the writers of rowops.hip's LayerNorm)
+__device__ __forceinline__ void ln_store_op(const GemmEpi& e, size_t m, int n, int N, const float4& v) {
   if (e.ln_op_kind == LNOP_H2) {
+    uint2 f16; unsigned hi8, lo8;
+    h2_quad(v, 1.0f, f16, hi8, lo8);
     char* row = reinterpret_cast<char*>(e.ln_op) + m * (size_t)e.ln_op_ld * 2;
-    *reinterpret_cast<uint2*>(row + 2 * n) = make_uint2(q.d0, q.d1);
+    *reinterpret_cast<uint2*>(row + 2 * n) = f16;
     char* p8 = row + h2_off8(N, n);
-    *reinterpret_cast<unsigned*>(p8) = q.d2;
-    *reinterpret_cast<unsigned*>(p8 + 16) = q.d3;
+    *reinterpret_cast<unsigned*>(p8) = hi8;
+    *reinterpret_cast<unsigned*>(p8 + 16) = lo8;
     return;
   }
+  uint2 hi;
+  hi.x = pack2bf(v.x, v.y);
+  hi.y = pack2bf(v.z, v.w);
   bf16_t* o = reinterpret_cast<bf16_t*>(e.ln_op) + m * (size_t)e.ln_op_ld + n;
-  *reinterpret_cast<uint2*>(o) = make_uint2(q.d0, q.d1);
-  if (e.ln_op_kind == LNOP_PAIR) *reinterpret_cast<uint2*>(o + (e.ln_op_ld >> 1)) = make_uint2(q.d2, q.d3);
-}
-#endif
-// host side: can the producer's operand copy go out as lane-pair 16-byte stores?
-inline bool gemm_epi_ln_ok(const GemmEpi& e, int N) {
-  if (!e.ln_part || !e.ln_op) return true;
-  return N % 8 == 0 && e.ln_op_ld % 8 == 0 && (reinterpret_cast<uintptr_t>(e.ln_op) & 15) == 0;
+  *reinterpret_cast<uint2*>(o) = hi;
+  if (e.ln_op_kind == LNOP_PAIR) {
+    uint2 lo;
+    lo.x = pack2bf(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = pack2bf(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
+    *reinterpret_cast<uint2*>(o + (e.ln_op_ld >> 1)) = lo;
+  }
 }
 
 // LNF: the folded-LayerNorm producer (GemmEpi::ln_part): every lane stays in the loop (columns n >= N contribute nothing) because the row
@@ -266,8 +214,6 @@ __device__ __forceinline__ void drain_resid(const char* sm, int pitch, const Gem
       if (LNF) kk[j] = reinterpret_cast<const float2*>(sm + (rb + (it + j) * STEP) * pitch + C4 * 16)->x;      // stage_row_stats
     }
     float2 mine = make_float2(0.f, 0.f);      // writer lanes: the sums of row wj of this batch
-    OpQuad opq = {0u, 0u, 0u, 0u};
-    static_assert(!LNF || RB % 2 == 0, "operand rows leave in pairs");
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
       if (!LNF && mm[j] >= M) continue;
@@ -280,14 +226,7 @@ __device__ __forceinline__ void drain_resid(const char* sm, int pitch, const Gem
       v.z = fmaf(v.z, cp.scale.z, r[j].z); v.w = fmaf(v.w, cp.scale.w, r[j].w);
       if (ok) *reinterpret_cast<float4*>(e.out_f32 + (size_t)mm[j] * e.ldc + n) = v;
       if (LNF) {
-        if (e.ln_op) {      // operand copy: rows j - 1 and j of the batch leave together (ln_store_op_pair)
-#ifndef DINODET_AB_NO_OP_PAIR
-          if ((j & 1) == 0) opq = ln_pack_op(e.ln_op_kind, v);
-          else ln_store_op_pair(e, mm[j - 1], mm[j], nv && mm[j - 1] < M, ok, n, N, opq, ln_pack_op(e.ln_op_kind, v));
-#else      // A/B builds only (tools/experiments): one 8-byte store per row visit, the first form of the fold
-          if (ok) ln_store_op_row(e, (size_t)mm[j], n, N, ln_pack_op(e.ln_op_kind, v));
-#endif
-        }
+        if (ok && e.ln_op) ln_store_op(e, (size_t)mm[j], n, N, v);
         const float a = v.x - kk[j], b = v.y - kk[j], c = v.z - kk[j], d = v.w - kk[j];
         const float sum = half32_sum_hi(nv ? (a + b) + (c + d) : 0.f);
         const float sq = half32_sum_hi(nv ? (a * a + b * b) + (c * c + d * d) : 0.f);

@@ -509,7 +509,6 @@ int launch_gemm_bf16_ppm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int
   if (N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
-  if (!gemm_epi_ln_ok(e, N)) return 2;
   ppm_attr();
   int gm = gemm_tile_mode();
   const int tiles = wres_grid(M, N, &gm);
@@ -526,7 +525,6 @@ int launch_gemm_x3_pp(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int 
   if (e.out_f32 && e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
-  if (!gemm_epi_ln_ok(e, N)) return 2;
   ppm_attr();
   int gm = gemm_tile_mode();
   const int tiles = wres_grid(M, N, &gm);
@@ -555,7 +553,6 @@ int launch_gemm_h2(const void* A, int lda, const void* W, int ldw, int M, int N,
   if (e.out_f32 && e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
-  if (!gemm_epi_ln_ok(e, N)) return 2;
   { const int No = e.glu ? N / 2 : N;     // columns of the output row (GemmEpi::glu: the gate halves them)
     if (e.out_h2 && (No % 32 != 0 || e.ldc < 2 * No || e.ldc % 8 != 0 || e.out_split != 0)) return 2;
     if (e.glu && e.out_h2 && (N % 8 != 0)) return 2; }

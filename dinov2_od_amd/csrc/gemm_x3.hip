@@ -177,7 +177,6 @@ int launch_gemm_x3(const bf16_t* A2, int lda, const bf16_t* W2, int ldw, int M, 
   if (e.out_f32 && e.ldc % 4 != 0) return 2;
   if (e.resid && e.ldr % 4 != 0) return 2;
   if (!e.out_f32 && !e.out_bf16) return 2;
-  if (!gemm_epi_ln_ok(e, N)) return 2;
   { const int t = gemm_tail_split(1, A2, lda, W2, ldw, M, N, K, e, s); if (t >= 0) return t; }
   {
     // the 8-wave ping-pong kernel (gemm_pp.hip) wherever a workgroup's K loop or column count is long enough to pay for its
