@@ -575,7 +575,7 @@ int tap(dod_handle* h, int stage, const void* src, bool src_bf16, size_t n, hipS
 int linear(dod_handle* h, bool bf, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const GemmEpi& e, hipStream_t s, int flops_K = 0) {
   ProfScope ps(h, s, bf ? PC_GEMM_BF16 : PC_GEMM_F32, 2.0 * M * N * (e.rows_per_img > 0 ? 3.0 * h->cfg.patch * h->cfg.patch : (double)(flops_K ? flops_K : K)));
   int r = bf ? launch_gemm_bf16((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, e, s)
-             : launch_gemm_f32((const float*)A, lda, (const float*)W, ldw, M, N, K, e, s);
+             : launch_gemm_f32((const float*)A, lda, (const float*)W, ldw, M, N, K, e, s, h->cfg.precision != DOD_PREC_FP32);      // (the strict mode keeps one k-ordered chain per output)
   if (r) return fail(h, r == 3 ? DOD_ERR_HIP : DOD_ERR_INVALID, "linear launch rejected (M=%d N=%d K=%d bf16=%d rc=%d)", M, N, K, (int)bf, r);
   return 0;
 }
@@ -1012,9 +1012,9 @@ int launch_widen_bf16(const bf16_t* in, float* out, size_t n, hipStream_t s) {
 
 // =========================================================================================== C ABI
 // ---- test hooks (dod_common.h DOD_OPT_*)
-static std::atomic<int> g_options[DOD_OPT_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static std::atomic<int> g_options[DOD_OPT_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 int dod_option(int which) { return which >= 0 && which < DOD_OPT_COUNT ? g_options[which].load() : -1; }
-static const char* const k_option_names[DOD_OPT_COUNT] = {"tailsplit", "dec_fused_split", "mha_chunk_images", "no_fused_patch", "ln_fold", "deterministic"};
+static const char* const k_option_names[DOD_OPT_COUNT] = {"tailsplit", "dec_fused_split", "mha_chunk_images", "no_fused_patch", "ln_fold", "deterministic", "f32_ksplit"};
 
 extern "C" {
 
@@ -1027,6 +1027,7 @@ int dod_test_set_option(const char* name, int value) {
 long dod_test_counter(const char* name) {
   if (name && !strcmp(name, "tail_splits")) return gemm_tail_split_count();
   if (name && !strcmp(name, "rem_cuts")) return gemm_rem_cut_count();
+  if (name && !strcmp(name, "f32_ksplits")) return gemm_f32_ksplit_count();
   return -1;
 }
 
@@ -1085,12 +1086,13 @@ int dod_set_weight(dod_handle* h, const char* key, const void* dev_ptr, const in
   return DOD_OK;
 }
 
-int dod_reserve_gemm_scratch(size_t bytes) { return gemm_tail_reserve(bytes) ? fail(nullptr, DOD_ERR_HIP, "scratch allocation of %zu bytes failed", bytes) : DOD_OK; }
+int dod_reserve_gemm_scratch(size_t bytes) { return (gemm_tail_reserve(bytes) || gemm_f32_ksplit_reserve()) ? fail(nullptr, DOD_ERR_HIP, "scratch allocation of %zu bytes failed", bytes) : DOD_OK; }
 
 int dod_finalize_weights(dod_handle* h, void* stream) {
   if (!h) return fail(nullptr, DOD_ERR_INVALID, "null handle");
   { static const size_t mb = [] { const char* v = getenv("DINODET_GEMM_SCRATCH_MB"); return v && atoi(v) > 0 ? (size_t)atoi(v) : (size_t)64; }();
-    (void)gemm_tail_reserve(mb << 20); }     // K-split scratch of the GEMMs' wave-quantisation tail (gemm_pp.hip): never allocated inside a forward
+    (void)gemm_tail_reserve(mb << 20);
+    (void)gemm_f32_ksplit_reserve(); }     // K-split scratch of the GEMMs' wave-quantisation tail (gemm_pp.hip): never allocated inside a forward
   int rc = finalize_impl(h, (hipStream_t)stream);
   if (rc || !h->has_dec) return rc;
   // layer 0's image-independent prefix (dod_handle::l0_tgt / l0_proj) through the forward's own code path, one image, scratch freed afterwards

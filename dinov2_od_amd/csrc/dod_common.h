@@ -25,6 +25,7 @@ enum { DOD_OPT_TAILSPLIT = 0,         // GEMM wave-quantisation tail split: 0 of
        DOD_OPT_NO_FUSED_PATCH,        // 1 = pack for the explicit im2col + GEMM patch embedding instead of the fused kernel (read at dod_finalize_weights)
        DOD_OPT_LN_FOLD,               // 0 = LayerNorm kernels instead of the folded form (read at dod_finalize_weights)
        DOD_OPT_DETERMINISTIC,         // 1 = ordered reductions instead of fp32 atomics in the training step's weight gradients
+       DOD_OPT_F32_KSPLIT,            // fp32 GEMM K split across workgroups (gemm_f32.hip): 0 = never, 1 = also for the operator dod_op_linear
        DOD_OPT_COUNT };
 int dod_option(int which);            // dod_api.hip; -1 when unset
 long gemm_tail_split_count();         // gemm_pp.hip: GEMM calls that took the tail-split path so far
@@ -211,7 +212,9 @@ inline GemmEpi gemm_epi_rows(const GemmEpi& e, int m0) {
 int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K,
                      const GemmEpi& e, hipStream_t s);
 int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K,
-                    const GemmEpi& e, hipStream_t s);
+                    const GemmEpi& e, hipStream_t s, bool allow_ksplit = false);      // allow_ksplit: gemm_f32.hip "K split across workgroups" (never in the strict fp32 mode)
+int gemm_f32_ksplit_reserve();      // scratch of that split; outside any stream capture
+long gemm_f32_ksplit_count();
 // The same exact-fp32 MFMA main loop for the training step's products (dec_train.hip): either operand may be given k-major
 // ([K, rows]: the transposed products of a backward need no transposed copies), a two-level batch (image, head) walks strided views
 // (attention scores / context / their adjoints as batched GEMMs), the K range may be split over grid.z with an atomic accumulate.

@@ -15,8 +15,10 @@
 // k-tiles per LDS stage and barrier -- a lone workgroup's k-tile takes ~1 us whatever is in flight behind it, co-resident
 // workgroups are what overlap it.
 #include "dod_common.h"
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #define FBM 64
 #define FBN 64
@@ -126,11 +128,18 @@ inline bool vec_ok(const void* p, long long ld, long long s1 = 0, long long s2 =
 
 }  // namespace
 
+// K split across workgroups (round 4).  A 64x64 tile walking K = 768 is 384 dependent v_mfma_f32_32x32x2_f32 per wave -- 24.6 k matrix-pipe cycles,
+// 13-16 us at the clock these kernels hold, whatever else happens -- and the decoder's small linears ([B*Q, 768] x [768 | 50 | 91, 768]^T at
+// B*Q = 400 .. 3 200 rows) put 2-156 such tiles on 256 CUs.  grid.y = S slices of the k-tiles; every slice stores its 64x64 partial
+// ([slice][tile][16 registers][256 threads]: coalesced), the LAST workgroup to arrive at a tile (one atomic counter per tile, reset by that
+// workgroup) sums the S partials IN SLICE ORDER -- so the result does not depend on which one was last -- and runs the epilogue.
+// S is a function of (N, K) alone (launch_gemm_f32): a row's bits do not depend on the batch it is computed in.
 template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
                                                        const float* __restrict__ W, int ldw,
-                                                       int M, int N, int K, GemmEpi e) {
+                                                       int M, int N, int K, GemmEpi e, float* __restrict__ part, unsigned* __restrict__ counters) {
   __shared__ __attribute__((aligned(16))) float f32_smem[4 * FBK * FLD];     // sA[2] | sW[2]; the split-K epilogue's [64][65] tile
+  __shared__ unsigned s_last;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_m = (M + FBM - 1) / FBM;
@@ -142,8 +151,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  f32_mainloop(la, lw, 0, (K + FBK - 1) / FBK, reinterpret_cast<float (*)[FBK * FLD]>(f32_smem),
+  const int S = gridDim.y, nk = (K + FBK - 1) / FBK;
+  const int kt0 = (int)((long long)blockIdx.y * nk / S), kt1 = (int)((long long)(blockIdx.y + 1) * nk / S);
+  f32_mainloop(la, lw, kt0, kt1, reinterpret_cast<float (*)[FBK * FLD]>(f32_smem),
                reinterpret_cast<float (*)[FBK * FLD]>(f32_smem + 2 * FBK * FLD), acc);
+  if (S > 1) {
+    const size_t tiles = gridDim.x;
+    float* mine = part + ((size_t)blockIdx.y * tiles + blockIdx.x) * (16 * 256) + tid;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[r * 256] = acc[r];
+    __threadfence();                 // the partial is visible device-wide before this workgroup is counted
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = atomicAdd(&counters[blockIdx.x], 1u);
+      s_last = old == (unsigned)(S - 1);
+      if (old == (unsigned)(S - 1)) counters[blockIdx.x] = 0u;      // every slice has been counted: ready for the next launch on this stream
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                 // acquire: the other slices' partials
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int sl = 0; sl < S; ++sl) {
+      const float* p = part + ((size_t)sl * tiles + blockIdx.x) * (16 * 256) + tid;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += p[r * 256];
+    }
+  }
 
   const int lr = lane & 31, lh = lane >> 5;
   const int m = m0 + wm * 32 + lr;
@@ -175,13 +209,74 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
 }
 
+// ---- scratch of the K split: F32K_SLOTS slabs per device, one per launching stream (least recently used first, as gemm_pp.hip's tail scratch:
+// a forward may run as concurrent micro-batches on separate streams); a slab = F32K_TILES counters (zero between launches) + partials of at most
+// F32K_PARTS (tile, slice) pairs.  Allocated by gemm_f32_ksplit_reserve() outside any stream capture, never freed (captured graphs keep the addresses).
+#define F32K_SLOTS 4
+#define F32K_TILES 4096
+#define F32K_PARTS 1536
+static std::mutex g_f32k_mu;
+static char* g_f32k[16] = {};
+static hipStream_t g_f32k_owner[16][F32K_SLOTS] = {};
+static unsigned long long g_f32k_used[16][F32K_SLOTS] = {};
+static unsigned long long g_f32k_clock = 0;
+static constexpr size_t F32K_SLAB = (size_t)F32K_TILES * 4 + (size_t)F32K_PARTS * 16 * 256 * 4;
+int gemm_f32_ksplit_reserve() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 3;
+  std::lock_guard<std::mutex> lk(g_f32k_mu);
+  if (g_f32k[dev]) return 0;
+  char* blk = nullptr;
+  if (hipMalloc((void**)&blk, F32K_SLAB * F32K_SLOTS) != hipSuccess) return 3;
+  if (hipMemset(blk, 0, F32K_SLAB * F32K_SLOTS) != hipSuccess) { (void)hipFree(blk); return 3; }
+  g_f32k[dev] = blk;
+  return 0;
+}
+static char* f32k_slab(int dev, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_f32k_mu);
+  if (dev < 0 || dev >= 16 || !g_f32k[dev]) return nullptr;
+  int pick = -1;
+  for (int i = 0; i < F32K_SLOTS; ++i)
+    if (g_f32k_used[dev][i] && g_f32k_owner[dev][i] == s) { pick = i; break; }
+  if (pick < 0) {
+    pick = 0;
+    for (int i = 1; i < F32K_SLOTS; ++i)
+      if (g_f32k_used[dev][i] < g_f32k_used[dev][pick]) pick = i;
+    g_f32k_owner[dev][pick] = s;
+  }
+  g_f32k_used[dev][pick] = ++g_f32k_clock;
+  return g_f32k[dev] + (size_t)pick * F32K_SLAB;
+}
+static std::atomic<long> g_f32k_count{0};
+long gemm_f32_ksplit_count() { return g_f32k_count.load(); }
+
 int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K,
-                    const GemmEpi& e, hipStream_t s) {
+                    const GemmEpi& e, hipStream_t s, bool allow_ksplit) {
   if (M <= 0 || N <= 0 || K <= 0) return 1;
   if (!e.out_f32 && !e.out_bf16) return 2;
-  const int tiles = ((M + FBM - 1) / FBM) * ((N + FBN - 1) / FBN);
-  if (vec_ok(A, lda) && vec_ok(W, ldw)) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tiles), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e);
-  else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(tiles), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e);
+  const int tiles_n = (N + FBN - 1) / FBN;
+  const int tiles = ((M + FBM - 1) / FBM) * tiles_n;
+  // Slices: from (N, K) alone -- the row count must not change a row's bits (micro-batches, single-image launches).  The callers that allow the
+  // split send at most ~16 m-tiles of N >= 128 here (larger row counts take the bf16 split-3 form, dod_api.hip qlinear) and any number for the
+  // narrow heads (N < 128): aim at two workgroups per CU for 16 m-tiles, at least 8 k-tiles per slice, at most 8 slices.
+  int S = 1;
+  float* part = nullptr; unsigned* counters = nullptr;
+  static const int mode = [] { const char* v = DOD_TUNE_ENV("DINODET_F32_KSPLIT"); return v ? atoi(v) : 1; }();      // tuning builds: 0 = off
+  { const int opt = dod_option(DOD_OPT_F32_KSPLIT); if (opt == 0) allow_ksplit = false; else if (opt == 1) allow_ksplit = true; }      // test hook
+  if (allow_ksplit && mode && e.rows_per_img == 0) {
+    const int nk = (K + FBK - 1) / FBK;
+    int want = (512 + 8 * tiles_n) / (16 * tiles_n);      // rounded: N = 768 (12 n-tiles) -> 3
+    want = want > 8 ? 8 : want;
+    want = want > nk / 8 ? nk / 8 : want;
+    if (want >= 2 && tiles <= F32K_TILES && (long)tiles * want <= F32K_PARTS) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      char* slab = f32k_slab(dev, s);
+      if (slab) { S = want; counters = reinterpret_cast<unsigned*>(slab); part = reinterpret_cast<float*>(slab + (size_t)F32K_TILES * 4); ++g_f32k_count; }
+    }
+  }
+  if (vec_ok(A, lda) && vec_ok(W, ldw)) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tiles, S), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e, part, counters);
+  else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(tiles, S), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e, part, counters);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -388,7 +388,7 @@ int dod_backbone_tail_train_backward(const dod_config* cfg, const dod_bb_tail_pa
                                      const void* tape, size_t tape_bytes, const dod_bb_tail_params* grads, void* workspace,
                                      size_t workspace_bytes, void* stream);
 
-/* Scratch of the GEMMs' wave-quantisation tail split (K-split partial slabs; gemm_pp.hip).  dod_finalize_weights reserves 64 MiB on the
+/* Scratch of the GEMMs' wave-quantisation tail split (K-split partial slabs; gemm_pp.hip) and of the fp32 GEMM's K split (gemm_f32.hip, fixed size).  dod_finalize_weights reserves 64 MiB on the
  * current device; operator-level callers (tests, tools) reserve it themselves.  Never allocated inside a forward / stream capture. */
 int dod_reserve_gemm_scratch(size_t bytes);
 /* Test hooks.  Process-wide integer options a parity test sets for its own cases and hands back with -1 (= the shipped behaviour); they
@@ -399,8 +399,10 @@ int dod_reserve_gemm_scratch(size_t bytes);
  *   "no_fused_patch"   1 = the explicit im2col + GEMM patch embedding (read by dod_finalize_weights)
  *   "ln_fold"          0 = LayerNorm kernels instead of the folded form (read by dod_finalize_weights)
  *   "deterministic"    1 = ordered reductions instead of fp32 atomics in the training step's weight gradients (also DINODET_DETERMINISTIC=1)
+ *   "f32_ksplit"       fp32 GEMM K split across workgroups (gemm_f32.hip): 0 = never, 1 = also in dod_op_linear (shipped: the decoder's small linears in
+ *                      every mode but the strict fp32 one)
  * dod_test_counter("tail_splits"): GEMM calls that took the tail-split path so far; "rem_cuts": GEMM calls whose short last round ran as a
- * launch of its own (gemm_bf16.hip); -1 for an unknown name.
+ * launch of its own (gemm_bf16.hip); "f32_ksplits": fp32 GEMM launches that split K across workgroups (gemm_f32.hip); -1 for an unknown name.
  * The in-kernel time stamps, the register-only MFMA probes and every tile / schedule override of the tuning rounds exist only in
  * -DDINODET_TUNING builds (include/dinodet_tuning.h); the release library exports none of them. */
 int dod_test_set_option(const char* name, int value);

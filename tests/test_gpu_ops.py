@@ -63,6 +63,40 @@ def test_linear_f32_all_epilogues(G, M, N, K):
         assert rel_err(out.cpu().numpy(), want.numpy()) < 3e-6, act
 
 
+@pytest.mark.parametrize("M,N,K", [(50, 50, 768), (400, 768, 768), (800, 91, 768), (800, 768, 3072), (3200, 4, 384), (333, 200, 132), (100, 256, 768),
+                                   (6400, 50, 768)])
+def test_linear_f32_k_split_across_workgroups(G, M, N, K):
+    """gemm_f32.hip, round 4: the decoder's small linears split K over grid.y; the last workgroup to arrive at a tile sums the slices in slice
+    order.  Same values as the unsplit kernel to fp32 rounding, every epilogue; identical from launch to launch (the counters reset themselves);
+    and the slice count is a function of (N, K) alone, so a row's bits do not depend on the number of rows launched with it."""
+    L = nat.lib()
+    nat.check(L.dod_reserve_gemm_scratch(1 << 20))
+    A, W = _n("k.A", (M, K)), _n("k.W", (N, K), 0.05)
+    bias, scale, resid = _n("k.b", (N,)), 1 + _n("k.s", (N,), 0.1), _n("k.r", (M, N))
+    ref = torch.from_numpy(A).double() @ torch.from_numpy(W).double().t()
+    Ad, Wd, bd, sd, rd = G.to_gpu(A), G.to_gpu(W), G.to_gpu(bias), G.to_gpu(scale), G.to_gpu(resid)
+    tn, nk = (N + 63) // 64, (K + 15) // 16
+    slices = min(8, (512 + 8 * tn) // (16 * tn), nk // 8)
+    try:
+        nat.set_option("f32_ksplit", 0)
+        base = {act: G.op_linear(Ad, Wd, bd, sd, rd, act).clone() for act in ("none", "relu", "sigmoid")}
+        nat.set_option("f32_ksplit", 1)
+        n0 = L.dod_test_counter(b"f32_ksplits")
+        for act, fn in (("none", lambda t: t), ("relu", torch.relu), ("sigmoid", torch.sigmoid)):
+            want = fn(ref + torch.from_numpy(bias).double()) * torch.from_numpy(scale).double() + torch.from_numpy(resid).double()
+            got = G.op_linear(Ad, Wd, bd, sd, rd, act).clone()
+            again = G.op_linear(Ad, Wd, bd, sd, rd, act)
+            assert torch.equal(got, again), act
+            assert rel_err(got.cpu().numpy(), want.numpy()) < 3e-6, act
+            assert rel_err(got.cpu().numpy(), base[act].cpu().numpy()) < 1e-6, act
+        assert L.dod_test_counter(b"f32_ksplits") - n0 == (6 if slices >= 2 else 0)
+        if M >= 100:      # the first 37 rows alone: the same bits
+            part = G.op_linear(Ad[:37].contiguous(), Wd, bd, sd, rd[:37].contiguous(), "relu")
+            assert torch.equal(part, G.op_linear(Ad, Wd, bd, sd, rd, "relu")[:37])
+    finally:
+        nat.set_option("f32_ksplit", -1)
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 4, 64), (128, 128, 64), (257, 384, 128), (1370, 768, 640), (2740, 2304, 768), (1111, 200, 3072)])
 def test_linear_bf16_all_epilogues(G, M, N, K):
     A = torch.from_numpy(_n("b.A", (M, K))).to(torch.bfloat16)
