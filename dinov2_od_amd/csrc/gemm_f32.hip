@@ -158,24 +158,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   if (S > 1) {
     const size_t tiles = gridDim.x;
     float* mine = part + ((size_t)blockIdx.y * tiles + blockIdx.x) * (16 * 256) + tid;
+    // No device-scope FENCE anywhere here: on this chip (eight XCDs, an L2 each) `__threadfence()` writes back and invalidates the whole L2 of the
+    // XCD -- inside a forward whose L2s are full of dirty activations that cost 17 % of the 8-image step.  The partials instead travel as
+    // agent-scope atomic stores / loads (sc1: written through to, and read from, the level all XCDs share); a wave's stores have completed
+    // there when its vmcnt reaches 0, which every wave waits for before the barrier that precedes the tile's counter increment.
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mine[r * 256] = acc[r];
-    __threadfence();                 // the partial is visible device-wide before this workgroup is counted
+    for (int r = 0; r < 16; ++r) __hip_atomic_store(mine + r * 256, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      const unsigned old = atomicAdd(&counters[blockIdx.x], 1u);
+      const unsigned old = __hip_atomic_fetch_add(&counters[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = old == (unsigned)(S - 1);
-      if (old == (unsigned)(S - 1)) counters[blockIdx.x] = 0u;      // every slice has been counted: ready for the next launch on this stream
+      if (old == (unsigned)(S - 1)) __hip_atomic_store(&counters[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every slice counted: ready for the next launch on this stream
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();                 // acquire: the other slices' partials
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     for (int sl = 0; sl < S; ++sl) {
       const float* p = part + ((size_t)sl * tiles + blockIdx.x) * (16 * 256) + tid;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += p[r * 256];
+      for (int r = 0; r < 16; ++r) acc[r] += __hip_atomic_load(p + r * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
@@ -265,7 +268,8 @@ int launch_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int
   { const int opt = dod_option(DOD_OPT_F32_KSPLIT); if (opt == 0) allow_ksplit = false; else if (opt == 1) allow_ksplit = true; }      // test hook
   if (allow_ksplit && mode && e.rows_per_img == 0) {
     const int nk = (K + FBK - 1) / FBK;
-    int want = (512 + 8 * tiles_n) / (16 * tiles_n);      // rounded: N = 768 (12 n-tiles) -> 3
+    const int target = mode > 1 ? mode : 512;      // workgroups aimed at for 16 m-tiles (tuning builds: DINODET_F32_KSPLIT = that number)
+    int want = (target + 8 * tiles_n) / (16 * tiles_n);      // rounded: N = 768 (12 n-tiles) -> 3
     want = want > 8 ? 8 : want;
     want = want > nk / 8 ? nk / 8 : want;
     if (want >= 2 && tiles <= F32K_TILES && (long)tiles * want <= F32K_PARTS) {
