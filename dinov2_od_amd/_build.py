@@ -28,11 +28,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
          "-I" + os.path.join(ROOT, "include")]
 
 
-# per-source extra flags (tuning: DINODET_ATTN_NOSLP=1 builds the attention kernels without SLP vectorisation -- hipcc packs adjacent
-# fp32 adds / multiplies of the softmax into v_pk_*_f32, which issue slower beside MFMAs than the scalar forms)
-EXTRA = {}
-if os.environ.get("DINODET_ATTN_NOSLP") == "1":
-    EXTRA = {"attn_bf16.hip": ["-fno-slp-vectorize"], "attn_x3.hip": ["-fno-slp-vectorize"]}
+# per-source extra flags.  The flash attention kernels are built WITHOUT SLP vectorisation: hipcc packs adjacent fp32 adds / multiplies /
+# fmas of the softmax into v_pk_*_f32, and on gfx950 packed fp32 does not overlap an executing MFMA (it takes the sum of the two times,
+# tools/probes/mfma_valu_overlap.hip, profiles/r04_mfma_valu_overlap_probe.txt) while plain VALU does.
+EXTRA = {"attn_bf16.hip": ["-fno-slp-vectorize"], "attn_x3.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

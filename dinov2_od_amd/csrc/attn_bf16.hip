@@ -75,31 +75,28 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     m_run[q] = m_new;
     const float nm = -m_new;
     float lsum;
-    {
-      typedef float f32x2_ __attribute__((ext_vector_type(2)));
-      const f32x2_ c2 = {c, c}, nm2 = {nm, nm};
-      f32x2_ ls[2] = {{0.f, 0.f}, {0.f, 0.f}};      // row sum on v_pk_add_f32, each exponential pair summed where it is produced
+    {      // Plain fp32 VALU only (one value per lane), and the file is built with -fno-slp-vectorize (_build.py) so that hipcc does not re-pack it:
+           // `tools/probes/mfma_valu_overlap.hip` (profiles/r04_mfma_valu_overlap_probe.txt) shows that v_pk_*_f32 does NOT overlap an executing MFMA
+           // on this part -- a wave of v_pk_fma_f32 beside a wave of MFMAs on the same SIMD takes the SUM of their times, and with two waves per
+           // SIMD the packed form has no throughput advantage either (4 cycles per instruction against 2 for the plain one) -- while plain VALU,
+           // v_exp_f32, v_max3_f32 and v_cvt_pk_bf16_f32 do overlap it.  Rounds 2-3 had forced v_pk_fma / v_pk_add / v_pk_mul here (fewer
+           // instructions: 376 against 420 per tile); this form is 4 % faster (6.06 -> 5.83 ms of attention per batch-64 step).
+      float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {   // v_pk_fma_f32: two scores per VALU issue slot
-          f32x2_ v = {s[q][kb][r], s[q][kb][r + 1]};
-          v = __builtin_elementwise_fma(v, c2, nm2);
-          f32x2_ ev;
-          ev.x = __builtin_amdgcn_exp2f(v.x);
-          ev.y = __builtin_amdgcn_exp2f(v.y);
-          asm("s_nop 0\n\tv_pk_add_f32 %0, %1, %0" : "+v"(ls[kb]) : "v"(ev));     // hipcc splits a C-level packed add next to MFMAs into two v_add_f32; s_nop: the hazard recogniser does not look into inline asm, and a VALU read of a v_exp_f32 result needs one wait state
-          s[q][kb][r] = ev.x;
-          s[q][kb][r + 1] = ev.y;
+        for (int r = 0; r < 16; r += 4) {
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(s[q][kb][r], c, nm)), e1 = __builtin_amdgcn_exp2f(fmaf(s[q][kb][r + 1], c, nm));
+          const float e2 = __builtin_amdgcn_exp2f(fmaf(s[q][kb][r + 2], c, nm)), e3 = __builtin_amdgcn_exp2f(fmaf(s[q][kb][r + 3], c, nm));
+          l0 += e0; l1 += e1; l2 += e2; l3 += e3;
+          s[q][kb][r] = e0; s[q][kb][r + 1] = e1; s[q][kb][r + 2] = e2; s[q][kb][r + 3] = e3;
         }
-      const f32x2_ l2 = ls[0] + ls[1];
-      lsum = l2.x + l2.y;
+      lsum = (l0 + l1) + (l2 + l3);
     }
     l_run[q] = fmaf(l_run[q], alpha, lsum);   // per-half partial; the halves are combined once at the end
-    // (a thresholded "lazy" rescale behind a wave-uniform branch was measured 4 % SLOWER: the branch splits the
-    //  scheduling region; the unconditional 16 packed multiplies are cheaper)
-    o[q][0] *= alpha;
-    o[q][1] *= alpha;
+    // (a thresholded "lazy" rescale behind a wave-uniform branch was measured 4 % SLOWER: the branch splits the scheduling region)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[q][0][r] *= alpha; o[q][1][r] *= alpha; }
     // P^T fragments: accumulator registers 8u..8u+7 of key block kb are the B operand of k-step 2kb+u
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {

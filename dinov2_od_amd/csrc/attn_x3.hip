@@ -90,8 +90,8 @@ __device__ __forceinline__ void x3_tile(const char* st, const bf16x8 (&qh)[4], c
       lsum += s[kb][r];
     }
   l_run = fmaf(l_run, alpha, lsum);
-  o[0] *= alpha;
-  o[1] *= alpha;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }      // per element: a vector multiply becomes v_pk_mul_f32, which does not overlap the MFMAs (attn_bf16.hip)
   // P^T fragments, split: accumulator registers 8u..8u+7 of key block kb are the B operand of k-step 2kb+u
   bf16x8 ph[4], pl[4];
 #pragma unroll
