@@ -336,6 +336,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fused_kernel(const bf16_t* _
   else attn_bf16_body<1, MX>((int)blockIdx.x - main_blocks, qkv, ctx, N, heads, npairs, scale_log2e, q_main, N, bs);
 }
 
+// (Round 4 built a 512-thread PING-PONG form of this kernel -- both waves of every SIMD in one workgroup, phased against each other with the
+// workgroup barrier so that one group's MFMA phase (P V of the previous tile, K Q^T of the next) meets the other group's softmax; the groups split
+// the keys and merge (m, l, O) through LDS at the end.  The probe says such phases overlap (tools/probes/mfma_valu_overlap.hip mode 16: 1 088 /
+// 1 974 cycles side by side); the kernel was parity-green and 26 % SLOWER (attention 6.52 -> 8.25 ms per batch-64 step, tools/experiments/r4_exp19.sh):
+// one workgroup per CU (2 x 48 KiB of rings) exposes every workgroup's prologue and merge, the MFMA phase carries six LDS round trips that two
+// free-running workgroups hide from each other, and every phase lasts as long as its slower half.  Not kept.)
 #ifdef DINODET_TUNING
 extern "C" int dod_debug_attn_stamps(void* dev_buf) {
   unsigned long long* p = (unsigned long long*)dev_buf;

@@ -158,10 +158,14 @@ def _attn_ref(q, k, v, scale):
     return torch.softmax(s, -1) @ v.double()
 
 
-@pytest.mark.parametrize("B,N,heads", [(1, 17, 2), (2, 64, 1), (2, 257, 6), (1, 1370, 12), (3, 130, 2)])
+# the last five reach the 512-thread ping-pong kernel (heads * B * ceil(N / 256) >= 1024): an even and an odd number of key tiles (22, 23; the two
+# wave groups split the keys), the short-tail launch form (1370 = 5 x 256 + 90), a partial last block without it (577), ONE key tile (group 1 idle)
+@pytest.mark.parametrize("B,N,heads", [(1, 17, 2), (2, 64, 1), (2, 257, 6), (1, 1370, 12), (3, 130, 2),
+                                       (16, 1370, 12), (15, 1440, 12), (32, 577, 12), (130, 60, 8), (43, 300, 12)])
 def test_attention_bf16(G, B, N, heads):
     D = heads * 64
-    qkv = torch.from_numpy(_n(f"a.qkv{N}", (B, N, 3 * D), 1.5)).to(torch.bfloat16)
+    rng = np.random.default_rng(B * 1000 + N)
+    qkv = torch.from_numpy((rng.standard_normal((B, N, 3 * D)) * 1.5).astype(np.float32)).to(torch.bfloat16)
     L = nat.lib()
     qd = qkv.to(G.dev()).contiguous()
     ctx = torch.empty(B, N, D, device=G.dev(), dtype=torch.bfloat16)
@@ -173,12 +177,15 @@ def test_attention_bf16(G, B, N, heads):
     assert float(np.abs(ctx.float().cpu().numpy() - want.numpy()).mean() / np.abs(want.numpy()).mean()) < 3e-3
 
 
-def test_attention_bf16_forced_rescale(G):
-    """Online-softmax rescale path: one key per later tile dominates every row (cdna guide rule 26)."""
-    B, N, heads, D = 1, 300, 1, 64
-    x = _n("a.spike", (B, N, 3 * D), 0.5)
-    x[0, 70, D:2 * D] *= 8.0      # key 70 (tile 1) spikes
-    x[0, 200, D:2 * D] *= 16.0    # key 200 (tile 3) spikes more
+@pytest.mark.parametrize("B,heads", [(1, 1), (300, 2)], ids=["4-wave", "ping-pong"])
+def test_attention_bf16_forced_rescale(G, B, heads):
+    """Online-softmax rescale path: one key per later tile dominates every row (cdna guide rule 26).  In the ping-pong kernel the spikes sit
+    in DIFFERENT wave groups' key halves (tiles 0-2 / 3-4), so the final merge has to rescale as well."""
+    N, D = 300, 64 * heads
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal((B, N, 3 * D)) * 0.5).astype(np.float32)
+    x[:, 70, D:2 * D] *= 8.0      # key 70 (tile 1) spikes
+    x[:, 200, D:2 * D] *= 16.0    # key 200 (tile 3) spikes more
     qkv = torch.from_numpy(x).to(torch.bfloat16)
     qd = qkv.to(G.dev())
     ctx = torch.empty(B, N, D, device=G.dev(), dtype=torch.bfloat16)

@@ -17,6 +17,8 @@
 //  11  every wave: 256 x v_fma_f32 only;   12  every wave: 256 x v_pk_fma_f32 only
 //  13  every wave: 256 x v_exp_f32 only;   14  waves 0-3 256 x v_exp_f32 only, waves 4-7 256 x v_fma_f32 only
 //  15  every wave: 64 x v_exp_f32 + 256 x v_fma_f32 interleaved (1 : 4), no MFMA
+//  16  waves 0-3 MFMA only, waves 4-7 the interleaved 64 x v_exp_f32 + 256 x v_fma_f32 of mode 15 (a softmax beside another wave's MFMAs)
+//  17  waves 0-3 MFMA only, waves 4-7 256 x v_exp_f32 only
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -57,10 +59,14 @@ __global__ __launch_bounds__(512) void probe(int iters, unsigned long long* out,
         MFMA(acc2); if (MODE == 7) { SF(0); SF(1); SF(2); SF(3); SF(4); SF(5); SF(6); SF(7); } else { MX3(0); CVT(0); MX3(1); CVT(1); MX3(2); CVT(2); MX3(3); CVT(3); }
         MFMA(acc3); if (MODE == 7) { SF(0); SF(1); SF(2); SF(3); SF(4); SF(5); SF(6); SF(7); } else { MX3(4); CVT(4); MX3(5); CVT(5); MX3(6); CVT(6); MX3(7); CVT(7); }
       }
-    } else if (MODE == 13 || MODE == 14 || MODE == 15) {
+    } else if ((MODE == 16 || MODE == 17) && wid < 4) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) { MFMA(acc0); MFMA(acc1); MFMA(acc2); MFMA(acc3); }
+      asm volatile("" ::: "memory");
+    } else if (MODE == 13 || MODE == 14 || MODE == 15 || MODE == 16 || MODE == 17) {
 #pragma unroll
       for (int g = 0; g < 32; ++g) {
-        if (MODE == 13 || (MODE == 14 && wid < 4)) { EXP2(0); EXP2(1); EXP2(2); EXP2(3); EXP2(4); EXP2(5); EXP2(6); EXP2(7); }
+        if (MODE == 13 || MODE == 17 || (MODE == 14 && wid < 4)) { EXP2(0); EXP2(1); EXP2(2); EXP2(3); EXP2(4); EXP2(5); EXP2(6); EXP2(7); }
         else if (MODE == 14) { SF(0); SF(1); SF(2); SF(3); SF(4); SF(5); SF(6); SF(7); }
         else { EXP2(g & 7); SF(0); SF(1); SF(2); SF(3); EXP2((g + 4) & 7); SF(4); SF(5); SF(6); SF(7); }
       }
@@ -152,5 +158,7 @@ int main(int argc, char** argv) {
   run<13>("256 v_exp_f32 only", iters, cus, d_out, d_sink);
   run<14>("waves 0-3 256 v_exp_f32 only, waves 4-7 256 plain v_fma_f32 only", iters, cus, d_out, d_sink);
   run<15>("64 v_exp_f32 + 256 plain v_fma_f32 interleaved, no MFMA", iters, cus, d_out, d_sink);
+  run<16>("waves 0-3 MFMA only, waves 4-7 64 exp + 256 plain fma interleaved", iters, cus, d_out, d_sink);
+  run<17>("waves 0-3 MFMA only, waves 4-7 256 v_exp_f32 only", iters, cus, d_out, d_sink);
   return 0;
 }
