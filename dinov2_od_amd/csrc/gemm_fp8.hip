@@ -342,6 +342,156 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
 #undef F8MX_PASS
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 256x256 tile, 16 waves (4 x 4, 64x64 each), ONE workgroup per CU, both operands block-scaled (round 4).  The 256x128 kernel above stages
+// (256 + 128) x 64 B per 256 x 128 x 64 MACs and two of them share a CU: 48 KB per 1 024 matrix-pipe cycles against the ~25 B/cycle a CU's
+// global->LDS path delivers -- its K loop is paced by staging at about half the fp8 MFMA rate.  This tile stages
+// (256 + 256) x 64 B for twice the MACs: 33 % fewer bytes per MAC.  Same per-wave arithmetic (2 x 2 blocks of v_mfma_scale_f32_32x32x64_f8f6f4,
+// the same fragment / scale lane maps), same 3-slot ring (3 x 32 KiB) and scale groups; per K-tile a wave issues ONE A piece and ONE W piece
+// (16 rows x 64 B each), and per group of four K-tiles waves 0-7 bring the A scales, waves 8-15 the W scales (one 4-byte-per-lane piece each:
+// every wave's vmcnt counts the same pieces).
+#define F8BN 256
+#define F8B_STAGE ((F8M + F8BN) * F8K)          // 32 KiB
+__global__ __launch_bounds__(1024, 1) void gemm_fp8mx_256x256_kernel(const unsigned char* __restrict__ A, int lda,
+                                                                     const unsigned char* __restrict__ W, int ldw,
+                                                                     int M, int N, int K, GemmEpi e, int GM) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int tiles_m = (M + F8M - 1) / F8M, tiles_n = (N + F8BN - 1) / F8BN;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  {
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = bid - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
+  const int m0 = tm * F8M, n0 = tn * F8BN;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const unsigned char* gA0; const unsigned char* gW0; const unsigned char* gS;
+  {
+    auto src = [&](const unsigned char* base, int ld, int r0, int piece, int lim) {
+      const int rl = piece * 16 + (lane >> 2);
+      int r = r0 + rl; r = r < lim ? r : lim - 1;
+      return base + (size_t)r * ld + swz64(rl, lane & 3) * 16;
+    };
+    gA0 = src(A, lda, m0, wid, M);
+    gW0 = src(W, ldw, n0, wid, N);
+    // scale piece of this wave: waves 0-7 the A rows, waves 8-15 the W rows; LDS dword index (wid & 7) * 64 + lane = tile row * 2 + half
+    const int sidx = (wid & 7) * 64 + lane;
+    if (wid < 8) { int r = m0 + (sidx >> 1); r = r < M ? r : M - 1; gS = e.a_bs + (size_t)r * (K >> 5) + (size_t)(sidx & 1) * (K >> 6); }
+    else { int r = n0 + (sidx >> 1); r = r < N ? r : N - 1; gS = e.w_bs + (size_t)r * (K >> 5) + (size_t)(sidx & 1) * (K >> 6); }
+  }
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  char* const sc_base = smem + F8_SLOTS * F8B_STAGE;                  // A scales: two 2-KiB buffers; W scales: two more behind them
+#define STAGE8B(slot_, k0)                                                                                 \
+  {                                                                                                        \
+    char* sA_ = smem + (slot_) * F8B_STAGE + wu * 1024;                                                    \
+    char* sW_ = smem + (slot_) * F8B_STAGE + F8M * F8K + wu * 1024;                                        \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (k0)), (lptr_t)(sA_), 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sW_), 16, 0, 0);                       \
+  }
+#define STAGE8BS(g_)                                                                                                                           \
+  __builtin_amdgcn_global_load_lds((gptr_t)(gS + 4 * (g_)), (lptr_t)(sc_base + (wu >> 3) * (2 * F8_SC_BYTES) + ((g_) & 1) * F8_SC_BYTES + (wu & 7) * 256), 4, 0, 0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = K / F8K, ng = nk >> 2;
+  const int lr = lane & 31, lh = lane >> 5;
+  STAGE8BS(0)
+  STAGE8B(0, 0)
+  STAGE8B(1, F8K)                      // nk >= 4
+  int offA[2], offW[2], offS[2], offSW[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 64 + i * 32 + lr;
+    offA[i] = row * 64 + swz64(row, lh) * 16;
+    offS[i] = (row * 2 + lh) * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offW[j] = F8M * F8K + row * 64 + swz64(row, lh) * 16; offSW[j] = 2 * F8_SC_BYTES + (row * 2 + lh) * 4; }
+  int slot = 0;
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  int sca[2] = {0, 0}, scw[2] = {0x7f7f7f7f, 0x7f7f7f7f};
+  for (int kt = 0; kt < nk; ++kt) {
+    const int u = kt & 3, g = kt >> 2;                 // wave-uniform
+    const bool has_next = g + 1 < ng;
+    // at the top of iteration kt everything issued in iteration kt - 1 may still fly: 2 ring pieces, plus the scale piece when kt - 1 opened a group
+    if (kt + 1 < nk) {
+      if (u == 1 && has_next) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (u == 0 && has_next) STAGE8BS(g + 1)
+    if (kt + 2 < nk) {
+      const int ns = slot >= 1 ? slot - 1 : 2;
+      STAGE8B(ns, (kt + 2) * F8K)
+    }
+    const char* st = smem + slot * F8B_STAGE;
+    if (u == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) sca[i] = __builtin_bit_cast(int, *reinterpret_cast<const us2*>(sc_base + (g & 1) * F8_SC_BYTES + offS[i]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) scw[j] = __builtin_bit_cast(int, *reinterpret_cast<const us2*>(sc_base + (g & 1) * F8_SC_BYTES + offSW[j]));
+    }
+    i32x8 af[2], wf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const i32x4 lo = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + offA[i]));
+      const i32x4 hi = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ 32)));
+      af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const i32x4 lo = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + offW[j]));
+      const i32x4 hi = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ 32)));
+      wf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int sb = (int)((unsigned)sca[i] >> (8 * u));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, (int)((unsigned)scw[j] >> (8 * u)), 0, sb);
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+#undef STAGE8B
+#undef STAGE8BS
+  constexpr int PITCH = F8BN * 4 + 16;
+  const ColParams cp = load_col_params<F8BN>(e, n0, N, tid);
+  const bool wide = drain8_ok(e, N);
+#define F8B_PASS(P)                                                                                                            \
+  {                                                                                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                              \
+    asm volatile("" ::: "memory");                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) stage_acc(smem, PITCH, wm * 32 + lr, wn * 64 + j * 32, acc[P][j], lh);       \
+    auto rowmap = [&](int row_l) { return m0 + (row_l >> 5) * 64 + (P) * 32 + (row_l & 31); };                                 \
+    __syncthreads();                                                                                                           \
+    if (e.out_bs) drain_glu_mx<128, F8BN, 1024>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);                                    \
+    else if (wide) drain_tile_bf16x8<128, F8BN, 1024>(smem, PITCH, e, M, N, n0, tid, rowmap);                                  \
+    else drain_tile<128, F8BN, 1024>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);                                               \
+  }
+  F8B_PASS(0)
+  F8B_PASS(1)
+#undef F8B_PASS
+}
+static constexpr int LDS8B = (128 * (F8BN * 4 + 16)) > (F8_SLOTS * F8B_STAGE + 4 * F8_SC_BYTES) ? (128 * (F8BN * 4 + 16)) : (F8_SLOTS * F8B_STAGE + 4 * F8_SC_BYTES);
+
 static constexpr int LDS8MX = F8_SLOTS * F8_STAGE + 2 * F8_SC_BYTES + 2 * F8_SCW_BYTES;
 static constexpr int LDS8 = (128 * (F8N * 4 + 16)) > F8_SLOTS * F8_STAGE ? (128 * (F8N * 4 + 16)) : F8_SLOTS * F8_STAGE;
 
@@ -353,6 +503,7 @@ static void fp8_attr() {      // > 64 KiB of dynamic LDS: once per DEVICE (a pro
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8MX);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8MX);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8B);
     attr_set[dev] = true;
   }
 }
@@ -372,6 +523,13 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
     fp8_attr();
     const int gm = N >= 3072 ? 8 : (N >= 2048 ? 4 : 2);
     const int tiles = ((M + F8M - 1) / F8M) * ((N + F8N - 1) / F8N);
+    // both operands block-scaled, a grid of several rounds of 256x256 tiles: the one-workgroup-per-CU tile (fewer staged bytes per MAC)
+    static const int big = [] { const char* v = DOD_TUNE_ENV("DINODET_FP8_TILE"); return v ? atoi(v) : 1; }();      // tuning builds: 0 = 256x128 everywhere
+    if (e.w_bs && big && M >= 4096 && N >= 512) {
+      const int tiles_b = ((M + F8M - 1) / F8M) * ((N + F8BN - 1) / F8BN);
+      hipLaunchKernelGGL(gemm_fp8mx_256x256_kernel, dim3(tiles_b), dim3(1024), LDS8B, s, A, lda, W, ldw, M, N, K, e, gm);
+      return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
     if (e.w_bs) hipLaunchKernelGGL(gemm_fp8mx_256x128_kernel<true>, dim3(tiles), dim3(512), LDS8MX, s, A, lda, W, ldw, M, N, K, e, gm);
     else hipLaunchKernelGGL(gemm_fp8mx_256x128_kernel<false>, dim3(tiles), dim3(512), LDS8MX, s, A, lda, W, ldw, M, N, K, e, gm);
     return hipGetLastError() == hipSuccess ? 0 : 3;

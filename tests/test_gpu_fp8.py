@@ -154,7 +154,9 @@ def test_linear_fp8_mx_block_scaled_activations(M, N, K):
     assert e_mx < 1.1 * e_row
 
 
-@pytest.mark.parametrize("M,N,K", [(515, 384, 1536), (4110 + 7, 1536, 4096), (300, 128, 256), (2740, 4608, 1536)])
+# from 4 096 rows up the 256x256 / 16-wave kernel takes these (gemm_fp8mx_256x256_kernel): a long K, a ragged N (2.5 tiles) with two scale groups,
+# a wide N with a ragged last m-tile
+@pytest.mark.parametrize("M,N,K", [(515, 384, 1536), (4110 + 7, 1536, 4096), (300, 128, 256), (2740, 4608, 1536), (4400, 640, 512), (8200 + 9, 4608, 1536)])
 def test_linear_fp8_mx_both_operands_block_scaled(M, N, K):
     """round 4: W block-scaled too (one e8m0 byte per 32 k on BOTH operands of v_mfma_scale_f32_32x32x64_f8f6f4): against the exact products
     of the same operands; blocks of very different magnitude along K in rows of A and of W -- a block / scale-byte mix-up on either side
@@ -186,6 +188,9 @@ def test_linear_fp8_mx_both_operands_block_scaled(M, N, K):
     assert err < ACC_TOL
     want = (ref + bias.double()) * scale.double() + resid.double()
     assert rel_err(run(bias.cuda(), scale.cuda(), resid.cuda()).cpu().numpy(), want.numpy()) < ACC_TOL
+    # bf16 output with a bias only: the 16-byte-store drain
+    got16 = run(bias.cuda(), out_dtype=torch.bfloat16).float().cpu().numpy()
+    assert rel_err(got16, (ref + bias.double()).numpy()) < 2 ** -7
     # the packer the forward uses for the weights (dod_op_quant_mx_fp8 on W) produces exactly these bytes
     qg, bg = mx_gpu(W.cuda())
     assert torch.equal(qg.cpu(), qw.view(torch.uint8)) and torch.equal(bg.cpu(), lay_w)
