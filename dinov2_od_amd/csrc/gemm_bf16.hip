@@ -364,7 +364,8 @@ int launch_gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, 
       }
       return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
     }
-    if (c_big <= c_small * 1.02) {
+    static const double m16_bias = [] { const char* v = DOD_TUNE_ENV("DINODET_GEMM_M16_BIAS"); return v ? atof(v) : 1.02; }();      // tuning builds: > 1 favours the 256x256 tiles
+    if (c_big <= c_small * m16_bias) {
       if (K >= 2048) return launch_gemm_bf16_ppm(A, lda, W, ldw, M, N, K, e, s);
       return launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, e, s);
     }
