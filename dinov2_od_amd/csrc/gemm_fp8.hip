@@ -525,7 +525,7 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
     const int tiles = ((M + F8M - 1) / F8M) * ((N + F8N - 1) / F8N);
     // both operands block-scaled, a grid of several rounds of 256x256 tiles: the one-workgroup-per-CU tile (fewer staged bytes per MAC)
     static const int big = [] { const char* v = DOD_TUNE_ENV("DINODET_FP8_TILE"); return v ? atoi(v) : 1; }();      // tuning builds: 0 = 256x128 everywhere
-    if (e.w_bs && big && M >= 4096 && N >= 512) {
+    if (e.w_bs && big && !(big == 2 && e.out_bs) && M >= 4096 && N >= 512) {      // (tuning value 2: not for the gated weights_in)
       const int tiles_b = ((M + F8M - 1) / F8M) * ((N + F8BN - 1) / F8BN);
       hipLaunchKernelGGL(gemm_fp8mx_256x256_kernel, dim3(tiles_b), dim3(1024), LDS8B, s, A, lda, W, ldw, M, N, K, e, gm);
       return hipGetLastError() == hipSuccess ? 0 : 3;
