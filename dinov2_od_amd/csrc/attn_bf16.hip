@@ -94,7 +94,9 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
       lsum = (l0 + l1) + (l2 + l3);
     }
     l_run[q] = fmaf(l_run[q], alpha, lsum);   // per-half partial; the halves are combined once at the end
-    // (a thresholded "lazy" rescale behind a wave-uniform branch was measured 4 % SLOWER: the branch splits the scheduling region)
+    // (a thresholded "lazy" rescale behind a wave-uniform branch -- the reference maximum moves only when a row's maximum exceeds it by 2^8 -- was
+    //  measured twice: 4 % slower on the packed form of round 3, 5 % slower on this one (attention 6.05 -> 6.38 ms, tools/experiments/r4_exp30.sh;
+    //  8 spilled registers): the branch splits the scheduling region, and the 64 multiplies it saves run beside the MFMAs anyway)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[q][0][r] *= alpha; o[q][1][r] *= alpha; }
     // P^T fragments: accumulator registers 8u..8u+7 of key block kb are the B operand of k-step 2kb+u
