@@ -88,6 +88,32 @@ def test_bench_self_launches_ranks_and_gathers(tmp_path):
     assert chk["all_in_gate"] and [r_["global_image"] for r_ in chk["ranks"]] == [0, 64]
 
 
+def test_bench_under_the_drivers_torchrun_command_four_ranks(tmp_path):
+    """the launch the driver uses at round end -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with N = 4 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, no self-launch):
+    one JSON line from rank 0, four ranks seen, every rank's shard timed and checked"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--rehearse-cpu", "--no-extras"], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 4 and j["config"]["n_ranks_seen"] == 4 and j["config"]["global_batch"] == 256 and j["scaling"] == "weak"
+    pr = j["per_rank"]
+    assert [r_["rank"] for r_ in pr["ms_per_step"]] == [0, 1, 2, 3]
+    assert pr["gpu_vs_oracle"]["all_in_gate"] and [r_["global_image"] for r_ in pr["gpu_vs_oracle"]["ranks"]] == [0, 64, 128, 192]
+
+
 def test_bench_fails_when_a_rank_leaves_the_gate(tmp_path):
     """a rank whose detections are wrong must fail the JOB (non-zero exit of `bench.py --gpus N`), not only show up in the JSON"""
     import json
