@@ -53,8 +53,9 @@ class Engine:
         # Graph replays of a large batch run it as `micro_streams` concurrent micro-batches on separate HIP streams (fork / join
         # inside the captured graph, one workspace each, one shared output buffer): images are independent, and one micro-batch's
         # LayerNorm / epilogue / last-round bubbles are filled by the other's GEMMs -- measured +4-5 % at batch 64 x 518^2 with
-        # bit-identical detections (tools/bench_two_streams.py); four micro-batches lose (1 993 vs 2 167 images/s) and a start skew
-        # between the streams (13 us .. 1.2 ms) changes nothing.  DINODET_MICRO_STREAMS=1 switches it off.
+        # bit-identical detections (tools/bench_two_streams.py); four micro-batches lose (1 993 vs 2 167 images/s), three too (round 4: 2 318
+        # vs 2 433), a start skew between the streams (13 us .. 1.2 ms) changes nothing, and neither do uneven halves (34 / 30 images: 2 435 vs
+        # 2 428; 36 / 28: 2 385; 40 / 24: 2 368 -- tools/experiments/r4_exp31.sh).  DINODET_MICRO_STREAMS=1 switches it off.
         self.micro_streams = max(1, int(os.environ.get("DINODET_MICRO_STREAMS", "2")))
         # threshold in TOKEN ROWS of the batch (images x tokens), not images: 16 images of 518^2 (ViT-L: 21 920 rows) gain 7 %, 8
         # images of 518^2 (10 960 rows: BASELINE configs[2] sharded over 8 GPUs) 10 %, 32 images of 224^2 (8 224 rows) nothing, 32
