@@ -343,18 +343,23 @@ __global__ __launch_bounds__(512, 4) void gemm_fp8mx_256x128_kernel(const unsign
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// 256x256 tile, 16 waves (4 x 4, 64x64 each), ONE workgroup per CU, both operands block-scaled (round 4).  The 256x128 kernel above stages
-// (256 + 128) x 64 B per 256 x 128 x 64 MACs and two of them share a CU: 48 KB per 1 024 matrix-pipe cycles against the ~25 B/cycle a CU's
-// global->LDS path delivers -- its K loop is paced by staging at about half the fp8 MFMA rate.  This tile stages
-// (256 + 256) x 64 B for twice the MACs: 33 % fewer bytes per MAC.  Same per-wave arithmetic (2 x 2 blocks of v_mfma_scale_f32_32x32x64_f8f6f4,
-// the same fragment / scale lane maps), same 3-slot ring (3 x 32 KiB) and scale groups; per K-tile a wave issues ONE A piece and ONE W piece
-// (16 rows x 64 B each), and per group of four K-tiles waves 0-7 bring the A scales, waves 8-15 the W scales (one 4-byte-per-lane piece each:
-// every wave's vmcnt counts the same pieces).
+// 256x256 tile, 16 waves (4 x 4, 64x64 each), ONE workgroup per CU, both operands block-scaled (round 4).  Same per-wave arithmetic as the 256x128
+// kernel above (2 x 2 blocks of v_mfma_scale_f32_32x32x64_f8f6f4, the same fragment / scale lane maps and scale groups); taken from 4 096 rows up.
+// Built for its staged bytes -- (256 + 256) x 64 B per 256 x 256 x 64 MACs, a third fewer per MAC than two co-resident 256x128 workgroups -- and
+// credited by the measurement with something else: alone it was 2 % slower, under two concurrent micro-batches 5.5-9 % faster, because
+// one-workgroup-per-CU grids of two streams interleave workgroup by workgroup (profiles/r04_fp8_256x256_ab.txt).  First form: 64-byte LDS rows,
+// three 32-KiB slots, a barrier per K-tile (commit 31578a1); this one has 128-BYTE rows: one K step = two 64-byte K-tiles (eight MFMAs per wave
+// and barrier instead of four), two 64-KiB slots (tile t + 1 streams in while tile t feeds the MFMAs: the bf16 16-wave kernel's protocol,
+// gemm_x3.hip PLAIN) -- fp8 GEMM class 72.6 -> 68.8 ms per ViT-g step, 330.7 -> 343.4 images/s on one box (tools/experiments/r4_exp32.sh).
+// The fragment of K-tile kk of a step is chunks 4 kk + g and 4 kk + g + 2 of the row (g = the lane half; MX lane map as above); with the
+// 128-byte-row swizzle (chunk ^= (row >> 1) & 7) those are the row's base offset XOR 64 kk and XOR 64 kk + 32.  A scale group (four K-tiles) is
+// two steps: waves 0-7 bring the A scales, waves 8-15 the W scales (one 4-byte-per-lane piece per group each).
 #define F8BN 256
-#define F8B_STAGE ((F8M + F8BN) * F8K)          // 32 KiB
-__global__ __launch_bounds__(1024, 1) void gemm_fp8mx_256x256_kernel(const unsigned char* __restrict__ A, int lda,
-                                                                     const unsigned char* __restrict__ W, int ldw,
-                                                                     int M, int N, int K, GemmEpi e, int GM) {
+#define F8CK 128
+#define F8C_STAGE ((F8M + F8BN) * F8CK)         // 64 KiB
+__global__ __launch_bounds__(1024, 1) void gemm_fp8mx_256x256x128_kernel(const unsigned char* __restrict__ A, int lda,
+                                                                         const unsigned char* __restrict__ W, int ldw,
+                                                                         int M, int N, int K, GemmEpi e, int GM) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
@@ -377,30 +382,31 @@ __global__ __launch_bounds__(1024, 1) void gemm_fp8mx_256x256_kernel(const unsig
   const int m0 = tm * F8M, n0 = tn * F8BN;
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  const unsigned char* gA0; const unsigned char* gW0; const unsigned char* gS;
+  const unsigned char* gA0; const unsigned char* gA1; const unsigned char* gW0; const unsigned char* gW1; const unsigned char* gS;
   {
-    auto src = [&](const unsigned char* base, int ld, int r0, int piece, int lim) {
-      const int rl = piece * 16 + (lane >> 2);
+    auto src = [&](const unsigned char* base, int ld, int r0, int piece, int lim) {      // piece = 8 rows x 128 B; the swizzle goes on the source chunk
+      const int rl = piece * 8 + (lane >> 3);
       int r = r0 + rl; r = r < lim ? r : lim - 1;
-      return base + (size_t)r * ld + swz64(rl, lane & 3) * 16;
+      return base + (size_t)r * ld + (((lane & 7) ^ ((rl >> 1) & 7)) * 16);
     };
-    gA0 = src(A, lda, m0, wid, M);
-    gW0 = src(W, ldw, n0, wid, N);
-    // scale piece of this wave: waves 0-7 the A rows, waves 8-15 the W rows; LDS dword index (wid & 7) * 64 + lane = tile row * 2 + half
+    gA0 = src(A, lda, m0, wid * 2, M); gA1 = src(A, lda, m0, wid * 2 + 1, M);
+    gW0 = src(W, ldw, n0, wid * 2, N); gW1 = src(W, ldw, n0, wid * 2 + 1, N);
     const int sidx = (wid & 7) * 64 + lane;
     if (wid < 8) { int r = m0 + (sidx >> 1); r = r < M ? r : M - 1; gS = e.a_bs + (size_t)r * (K >> 5) + (size_t)(sidx & 1) * (K >> 6); }
     else { int r = n0 + (sidx >> 1); r = r < N ? r : N - 1; gS = e.w_bs + (size_t)r * (K >> 5) + (size_t)(sidx & 1) * (K >> 6); }
   }
   const int wu = __builtin_amdgcn_readfirstlane(wid);
-  char* const sc_base = smem + F8_SLOTS * F8B_STAGE;                  // A scales: two 2-KiB buffers; W scales: two more behind them
-#define STAGE8B(slot_, k0)                                                                                 \
+  char* const sc_base = smem + 2 * F8C_STAGE;
+#define STAGE8C(slot_, k0)                                                                                 \
   {                                                                                                        \
-    char* sA_ = smem + (slot_) * F8B_STAGE + wu * 1024;                                                    \
-    char* sW_ = smem + (slot_) * F8B_STAGE + F8M * F8K + wu * 1024;                                        \
+    char* sA_ = smem + (slot_) * F8C_STAGE + wu * 2048;                                                    \
+    char* sW_ = smem + (slot_) * F8C_STAGE + F8M * F8CK + wu * 2048;                                       \
     __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (k0)), (lptr_t)(sA_), 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (k0)), (lptr_t)(sA_ + 1024), 16, 0, 0);                \
     __builtin_amdgcn_global_load_lds((gptr_t)(gW0 + (k0)), (lptr_t)(sW_), 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gW1 + (k0)), (lptr_t)(sW_ + 1024), 16, 0, 0);                \
   }
-#define STAGE8BS(g_)                                                                                                                           \
+#define STAGE8CS(g_)                                                                                                                           \
   __builtin_amdgcn_global_load_lds((gptr_t)(gS + 4 * (g_)), (lptr_t)(sc_base + (wu >> 3) * (2 * F8_SC_BYTES) + ((g_) & 1) * F8_SC_BYTES + (wu & 7) * 256), 4, 0, 0);
   f32x16 acc[2][2];
 #pragma unroll
@@ -409,73 +415,70 @@ __global__ __launch_bounds__(1024, 1) void gemm_fp8mx_256x256_kernel(const unsig
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int nk = K / F8K, ng = nk >> 2;
+  const int nks = K / F8CK, ng = nks >> 1;           // K % 256 == 0: whole scale groups
   const int lr = lane & 31, lh = lane >> 5;
-  STAGE8BS(0)
-  STAGE8B(0, 0)
-  STAGE8B(1, F8K)                      // nk >= 4
+  STAGE8CS(0)
+  STAGE8C(0, 0)
   int offA[2], offW[2], offS[2], offSW[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = wm * 64 + i * 32 + lr;
-    offA[i] = row * 64 + swz64(row, lh) * 16;
+    offA[i] = row * 128 + ((lh ^ ((row >> 1) & 7)) * 16);
     offS[i] = (row * 2 + lh) * 4;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offW[j] = F8M * F8K + row * 64 + swz64(row, lh) * 16; offSW[j] = 2 * F8_SC_BYTES + (row * 2 + lh) * 4; }
-  int slot = 0;
+  for (int j = 0; j < 2; ++j) {
+    const int row = wn * 64 + j * 32 + lr;
+    offW[j] = F8M * F8CK + row * 128 + ((lh ^ ((row >> 1) & 7)) * 16);
+    offSW[j] = 2 * F8_SC_BYTES + (row * 2 + lh) * 4;
+  }
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
   int sca[2] = {0, 0}, scw[2] = {0x7f7f7f7f, 0x7f7f7f7f};
-  for (int kt = 0; kt < nk; ++kt) {
-    const int u = kt & 3, g = kt >> 2;                 // wave-uniform
-    const bool has_next = g + 1 < ng;
-    // at the top of iteration kt everything issued in iteration kt - 1 may still fly: 2 ring pieces, plus the scale piece when kt - 1 opened a group
-    if (kt + 1 < nk) {
-      if (u == 1 && has_next) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+  for (int ks = 0; ks < nks; ++ks) {
+    const int g = ks >> 1, half = ks & 1;              // wave-uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile ks (and, at a group's first step, its scale dwords) has landed
+    __builtin_amdgcn_s_barrier();                      // ... for every wave; and every wave is done with tile ks - 1: its slot may be refilled
     asm volatile("" ::: "memory");
-    if (u == 0 && has_next) STAGE8BS(g + 1)
-    if (kt + 2 < nk) {
-      const int ns = slot >= 1 ? slot - 1 : 2;
-      STAGE8B(ns, (kt + 2) * F8K)
-    }
-    const char* st = smem + slot * F8B_STAGE;
-    if (u == 0) {
+    if (half == 0 && g + 1 < ng) STAGE8CS(g + 1)
+    if (ks + 1 < nks) STAGE8C((ks + 1) & 1, (ks + 1) * F8CK)
+    const char* st = smem + (ks & 1) * F8C_STAGE;
+    if (half == 0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) sca[i] = __builtin_bit_cast(int, *reinterpret_cast<const us2*>(sc_base + (g & 1) * F8_SC_BYTES + offS[i]));
 #pragma unroll
       for (int j = 0; j < 2; ++j) scw[j] = __builtin_bit_cast(int, *reinterpret_cast<const us2*>(sc_base + (g & 1) * F8_SC_BYTES + offSW[j]));
     }
-    i32x8 af[2], wf[2];
+#pragma unroll 1      // (unrolled, hipcc hoists both K-tiles' fragments above the first MFMA: 64 fragment + 64 accumulator registers, and spills)
+    for (int kk = 0; kk < 2; ++kk) {
+      const int u = half * 2 + kk;                     // K-tile within the scale group
+      i32x8 af[2], wf[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const i32x4 lo = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + offA[i]));
-      const i32x4 hi = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ 32)));
-      af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      for (int i = 0; i < 2; ++i) {
+        const i32x4 lo = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ (kk * 64))));
+        const i32x4 hi = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ (kk * 64 + 32))));
+        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const i32x4 lo = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ (kk * 64))));
+        const i32x4 hi = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ (kk * 64 + 32))));
+        wf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int sb = (int)((unsigned)sca[i] >> (8 * u));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, (int)((unsigned)scw[j] >> (8 * u)), 0, sb);
+      }
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const i32x4 lo = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + offW[j]));
-      const i32x4 hi = __builtin_bit_cast(i32x4, *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ 32)));
-      wf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int sb = (int)((unsigned)sca[i] >> (8 * u));
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, (int)((unsigned)scw[j] >> (8 * u)), 0, sb);
-    }
-    slot = slot == 2 ? 0 : slot + 1;
   }
-#undef STAGE8B
-#undef STAGE8BS
+#undef STAGE8C
+#undef STAGE8CS
   constexpr int PITCH = F8BN * 4 + 16;
   const ColParams cp = load_col_params<F8BN>(e, n0, N, tid);
   const bool wide = drain8_ok(e, N);
-#define F8B_PASS(P)                                                                                                            \
+#define F8C_PASS(P)                                                                                                            \
   {                                                                                                                            \
     __builtin_amdgcn_s_barrier();                                                                                              \
     asm volatile("" ::: "memory");                                                                                             \
@@ -486,11 +489,11 @@ __global__ __launch_bounds__(1024, 1) void gemm_fp8mx_256x256_kernel(const unsig
     else if (wide) drain_tile_bf16x8<128, F8BN, 1024>(smem, PITCH, e, M, N, n0, tid, rowmap);                                  \
     else drain_tile<128, F8BN, 1024>(smem, PITCH, e, cp, M, N, n0, tid, rowmap);                                               \
   }
-  F8B_PASS(0)
-  F8B_PASS(1)
-#undef F8B_PASS
+  F8C_PASS(0)
+  F8C_PASS(1)
+#undef F8C_PASS
 }
-static constexpr int LDS8B = (128 * (F8BN * 4 + 16)) > (F8_SLOTS * F8B_STAGE + 4 * F8_SC_BYTES) ? (128 * (F8BN * 4 + 16)) : (F8_SLOTS * F8B_STAGE + 4 * F8_SC_BYTES);
+static constexpr int LDS8C = 2 * F8C_STAGE + 4 * F8_SC_BYTES;      // 136 KiB (>= the epilogue's 133 KiB fp32 tile)
 
 static constexpr int LDS8MX = F8_SLOTS * F8_STAGE + 2 * F8_SC_BYTES + 2 * F8_SCW_BYTES;
 static constexpr int LDS8 = (128 * (F8N * 4 + 16)) > F8_SLOTS * F8_STAGE ? (128 * (F8N * 4 + 16)) : F8_SLOTS * F8_STAGE;
@@ -503,7 +506,7 @@ static void fp8_attr() {      // > 64 KiB of dynamic LDS: once per DEVICE (a pro
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8MX);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8MX);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8B);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8mx_256x256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8C);
     attr_set[dev] = true;
   }
 }
@@ -527,7 +530,7 @@ int launch_gemm_fp8(const unsigned char* A, int lda, const unsigned char* W, int
     static const int big = [] { const char* v = DOD_TUNE_ENV("DINODET_FP8_TILE"); return v ? atoi(v) : 1; }();      // tuning builds: 0 = 256x128 everywhere
     if (e.w_bs && big && !(big == 2 && e.out_bs) && M >= 4096 && N >= 512) {      // (tuning value 2: not for the gated weights_in)
       const int tiles_b = ((M + F8M - 1) / F8M) * ((N + F8BN - 1) / F8BN);
-      hipLaunchKernelGGL(gemm_fp8mx_256x256_kernel, dim3(tiles_b), dim3(1024), LDS8B, s, A, lda, W, ldw, M, N, K, e, gm);
+      hipLaunchKernelGGL(gemm_fp8mx_256x256x128_kernel, dim3(tiles_b), dim3(1024), LDS8C, s, A, lda, W, ldw, M, N, K, e, gm);
       return hipGetLastError() == hipSuccess ? 0 : 3;
     }
     if (e.w_bs) hipLaunchKernelGGL(gemm_fp8mx_256x128_kernel<true>, dim3(tiles), dim3(512), LDS8MX, s, A, lda, W, ldw, M, N, K, e, gm);
