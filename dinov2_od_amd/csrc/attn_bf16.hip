@@ -371,6 +371,15 @@ int launch_attn_bf16(const bf16_t* qkv, bf16_t* ctx, int B, int N, int heads, fl
     const int nqb = (q_main + AT_WAVES * 64 - 1) / (AT_WAVES * 64);
     static const char* fse = DOD_TUNE_ENV("DINODET_ATTN_FUSED_TAIL");      // "0": the two-launch form (A/B)
     if (split && !(fse && fse[0] == '0')) {
+#ifdef DINODET_TUNING
+      // tuning builds: DINODET_ATTN_LDS_PAD = bytes of unused dynamic LDS per workgroup (64 KiB leaves ONE workgroup per CU: one wave per SIMD)
+      static const int pad = [] { const char* v = getenv("DINODET_ATTN_LDS_PAD"); return v ? atoi(v) : 0; }();
+      if (pad > 0 && !mx) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+        hipLaunchKernelGGL(attn_bf16_fused_kernel<false>, dim3(pairs8 * nqb + pairs8), dim3(256), pad, s, qkv, ctx, N, heads, npairs, c, pairs8 * nqb, q_main, ctx_bs);
+        return hipGetLastError() == hipSuccess ? 0 : 3;
+      }
+#endif
       if (mx) hipLaunchKernelGGL(attn_bf16_fused_kernel<true>, dim3(pairs8 * nqb + pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, pairs8 * nqb, q_main, ctx_bs);
       else hipLaunchKernelGGL(attn_bf16_fused_kernel<false>, dim3(pairs8 * nqb + pairs8), dim3(256), 0, s, qkv, ctx, N, heads, npairs, c, pairs8 * nqb, q_main, ctx_bs);
     } else {
